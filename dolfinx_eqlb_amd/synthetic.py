@@ -1,0 +1,144 @@
+"""Synthetic, Galerkin-compatible input data for the equilibration (no DOLFINx/PETSc here).
+
+The interior patch problems of the semi-explicit equilibration are solvable only if the
+projected flux G and right-hand side f satisfy the hat-function orthogonality
+
+        (f, hat_a) + (G, grad hat_a) = 0      for every node a not on the primal Dirichlet
+                                              boundary (homogeneous flux BCs elsewhere),
+
+which a Galerkin solution u_h with G = -grad u_h provides.  Instead of solving the primal
+problem, arbitrary (G, f0) in DG_{k-1}^2 x DG_{k-1} are made compatible by a correction of f0
+in span{hat_b} (k >= 2; P1 mass-matrix solve) or span{Pi_0 hat_b} (k = 1), SURVEY.md 8(d).
+"""
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from .eqlb.check_eqlb_conditions import cell_geometry
+from .elmtlib.lagrange import Lagrange
+from .elmtlib.quadrature import make_quadrature_triangle
+
+
+def dg_points(mesh, degree):
+    """Physical coordinates of the DG_{degree} nodes of every cell: [ncells, nd, 2]."""
+    nodes = np.array([[float(a), float(b)] for a, b in Lagrange(degree).nodes])
+    J, _, _ = cell_geometry(mesh)
+    x0 = mesh.x[mesh.cell_nodes[:, 0], :2]
+    return x0[:, None, :] + np.einsum("cij,qj->cqi", J, nodes)
+
+
+def facet_types(mesh, neumann=None, nrhs=1):
+    """facet_type table [nrhs, nfacets]: 0 interior, 1 primal-Dirichlet, 2 flux-BC facets.
+    `neumann`: callable(midpoints[n,2]) -> bool mask selecting flux-BC boundary facets."""
+    ft = np.zeros((nrhs, mesh.nfacets), dtype=np.int8)
+    bf = mesh.boundary_facets()
+    ft[:, bf] = 1
+    if neumann is not None:
+        mask = neumann(mesh.facet_midpoints()[bf])
+        ft[:, bf[mask]] = 2
+    return ft
+
+
+def make_compatible_data(mesh, k, facet_type, degree_dg=None, seed=20241003, u_ext=None,
+                         grad_u_ext=None, f_ext=None, tol=1e-13):
+    """Returns (flux_dg [ncells*nd*2], rhs_dg [ncells*nd]) satisfying the orthogonality.
+
+    Default: smooth-plus-random data (random DG perturbation, so jumps of G are arbitrary).
+    With grad_u_ext/f_ext: G = -I_h(grad u_ext), f0 = I_h(f_ext) (interpolated fields).
+    """
+    degree_dg = k - 1 if degree_dg is None else degree_dg
+    rng = np.random.default_rng(seed)
+    dg = Lagrange(degree_dg)
+    nd = dg.ndofs
+    ncells, nnodes = mesh.ncells, mesh.nnodes
+    pts = dg_points(mesh, degree_dg)
+    if grad_u_ext is not None:
+        gx, gy = grad_u_ext(pts[..., 0], pts[..., 1])
+        G = -np.stack([gx, gy], axis=2)
+        f0 = f_ext(pts[..., 0], pts[..., 1])
+    else:
+        X, Y = pts[..., 0], pts[..., 1]
+        G = np.stack([-2 * np.pi * np.cos(2 * np.pi * X) * np.cos(2 * np.pi * Y),
+                      2 * np.pi * np.sin(2 * np.pi * X) * np.sin(2 * np.pi * Y)], axis=2)
+        G += 0.3 * rng.standard_normal(G.shape)
+        f0 = 8 * np.pi ** 2 * np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y)
+        f0 += 3.0 * rng.standard_normal(f0.shape)
+
+    J, detJ, K = cell_geometry(mesh)
+    adet = np.abs(detJ)
+    qp, qw = make_quadrature_triangle(2 * max(degree_dg, 1) + 2)
+    psi = dg.tabulate(qp)[0]  # [q, j]
+    hat = Lagrange(1)
+    hq = hat.tabulate(qp, 1)  # [3, q, 3]
+    # r_a = (f0, hat_a) + (G, grad hat_a), assembled over cells
+    Mfh = np.einsum("q,qj,qn->jn", qw, psi, hq[0])  # int psi_j hat_n (reference)
+    mpsi = np.einsum("q,qj->j", qw, psi)
+    ghat_ref = np.stack([hq[1][0], hq[2][0]], axis=1)  # [n, X] constant gradients
+    ghat = np.einsum("cXd,nX->cnd", K, ghat_ref)  # physical gradients [c, n, d]
+    r_loc = np.einsum("cj,jn->cn", f0, Mfh) * adet[:, None]
+    Gint = np.einsum("cjd,j->cd", G, mpsi) * adet[:, None]
+    r_loc += np.einsum("cd,cnd->cn", Gint, ghat)
+    r = np.zeros(nnodes)
+    np.add.at(r, mesh.cell_nodes.ravel(), r_loc.ravel())
+
+    # free nodes: not on a primal-Dirichlet facet (of RHS 0)
+    ft = np.asarray(facet_type).reshape(-1, mesh.nfacets)[0]
+    fixed = np.zeros(nnodes, dtype=bool)
+    fixed[mesh.facet_nodes[ft == 1].ravel()] = True
+    free = np.nonzero(~fixed)[0]
+
+    cn = mesh.cell_nodes
+    rows = np.repeat(cn, 3, axis=1).ravel()
+    cols = np.tile(cn, (1, 3)).ravel()
+    if degree_dg >= 1:
+        Mref = np.einsum("q,qn,qm->nm", qw, hq[0], hq[0])
+        vals = (adet[:, None, None] * Mref[None]).ravel()
+    else:
+        vals = np.repeat(adet / 18.0, 9)  # (Pi_0 hat_b, hat_a)_T = |T|/9, |T| = |detJ|/2
+    Mg = sp.csr_matrix((vals, (rows, cols)), shape=(nnodes, nnodes))
+    Mff = Mg[free][:, free].tocsr()
+    if free.size < 20000:
+        c_free = spla.spsolve(Mff.tocsc(), r[free])
+    else:
+        d = Mff.diagonal()
+        c_free, info = spla.cg(Mff, r[free], rtol=tol, atol=0.0, maxiter=2000,
+                               M=sp.diags(1.0 / d))
+        if info != 0:
+            raise RuntimeError("compatibilisation CG did not converge")
+    c = np.zeros(nnodes)
+    c[free] = c_free
+
+    # subtract sum_b c_b hat_b (resp. its cell mean) from f0, in DG nodal values
+    if degree_dg >= 1:
+        nodes = np.array([[float(a), float(b)] for a, b in dg.nodes])
+        hat_at_nodes = hat.tabulate(nodes)[0]  # [j, n]
+        f = f0 - np.einsum("jn,cn->cj", hat_at_nodes, c[cn])
+    else:
+        f = f0 - c[cn].sum(axis=1, keepdims=True) / 3.0
+    return np.ascontiguousarray(G.reshape(-1)), np.ascontiguousarray(f.reshape(-1))
+
+
+def compatibility_residual(mesh, k, facet_type, flux_dg, rhs_dg, degree_dg=None):
+    """max_a |(f, hat_a) + (G, grad hat_a)| over the free nodes (diagnostic)."""
+    degree_dg = k - 1 if degree_dg is None else degree_dg
+    dg = Lagrange(degree_dg)
+    J, detJ, K = cell_geometry(mesh)
+    adet = np.abs(detJ)
+    qp, qw = make_quadrature_triangle(2 * max(degree_dg, 1) + 2)
+    psi = dg.tabulate(qp)[0]
+    hq = Lagrange(1).tabulate(qp, 1)
+    f = rhs_dg.reshape(mesh.ncells, dg.ndofs)
+    G = flux_dg.reshape(mesh.ncells, dg.ndofs, 2)
+    Mfh = np.einsum("q,qj,qn->jn", qw, psi, hq[0])
+    mpsi = np.einsum("q,qj->j", qw, psi)
+    ghat_ref = np.stack([hq[1][0], hq[2][0]], axis=1)
+    ghat = np.einsum("cXd,nX->cnd", K, ghat_ref)
+    r_loc = np.einsum("cj,jn->cn", f, Mfh) * adet[:, None]
+    r_loc += np.einsum("cd,cnd->cn", np.einsum("cjd,j->cd", G, mpsi) * adet[:, None], ghat)
+    r = np.zeros(mesh.nnodes)
+    np.add.at(r, mesh.cell_nodes.ravel(), r_loc.ravel())
+    ft = np.asarray(facet_type).reshape(-1, mesh.nfacets)[0]
+    fixed = np.zeros(mesh.nnodes, dtype=bool)
+    fixed[mesh.facet_nodes[ft == 1].ravel()] = True
+    return float(np.max(np.abs(r[~fixed]))) if (~fixed).any() else 0.0

@@ -1,0 +1,165 @@
+"""TEST INFRASTRUCTURE - ctypes binding of the CPU oracle (oracle/eqlb_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .tables import Tables, make_tables
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+
+def build(force: bool = False):
+    """Compile the C restatement (gcc) into oracle/_build/."""
+    src = os.path.join(_HERE, "eqlb_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src),
+                                               os.path.getmtime(src[:-2] + ".h")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+class _Mesh(C.Structure):
+    _fields_ = [("nnodes", C.c_int32), ("ncells", C.c_int32), ("nfacets", C.c_int32),
+                ("x", C.c_void_p), ("cell_nodes", C.c_void_p), ("cell_facets", C.c_void_p),
+                ("facet_nodes", C.c_void_p), ("facet_cells_off", C.c_void_p),
+                ("facet_cells", C.c_void_p), ("node_cells_off", C.c_void_p),
+                ("node_cells", C.c_void_p), ("node_facets_off", C.c_void_p),
+                ("node_facets", C.c_void_p), ("facet_perm", C.c_void_p)]
+
+
+class _Tables(C.Structure):
+    _fields_ = [("k", C.c_int32), ("ndofs", C.c_int32), ("nd", C.c_int32), ("ndf", C.c_int32),
+                ("nq", C.c_int32), ("nqf", C.c_int32),
+                ("qpoints", C.c_void_p), ("qweights", C.c_void_p), ("flux_basis", C.c_void_p),
+                ("rhs_cell", C.c_void_p), ("rhs_fct", C.c_void_p), ("hat_cell", C.c_void_p),
+                ("hat_fct", C.c_void_p), ("M", C.c_void_p), ("doftrafo", C.c_void_p),
+                ("fct_normal_out", C.c_void_p), ("fct_dofs", C.c_void_p)]
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.oracle_se_reconstruct.restype = C.c_int
+        _lib.oracle_se_patch.restype = C.c_int
+        _lib.oracle_build_patches.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _mesh_struct(mesh):
+    keep = [np.ascontiguousarray(mesh.x, dtype=np.float64),
+            np.ascontiguousarray(mesh.cell_nodes, dtype=np.int32),
+            np.ascontiguousarray(mesh.cell_facets, dtype=np.int32),
+            np.ascontiguousarray(mesh.facet_nodes, dtype=np.int32),
+            np.ascontiguousarray(mesh.facet_cells_offsets, dtype=np.int32),
+            np.ascontiguousarray(mesh.facet_cells, dtype=np.int32),
+            np.ascontiguousarray(mesh.node_cells_offsets, dtype=np.int32),
+            np.ascontiguousarray(mesh.node_cells, dtype=np.int32),
+            np.ascontiguousarray(mesh.node_facets_offsets, dtype=np.int32),
+            np.ascontiguousarray(mesh.node_facets, dtype=np.int32),
+            np.ascontiguousarray(mesh.facet_perm, dtype=np.uint8)]
+    s = _Mesh(mesh.nnodes, mesh.ncells, mesh.nfacets, *[_p(a) for a in keep])
+    return s, keep
+
+
+def _tables_struct(t: Tables):
+    keep = [t.qpoints, t.qweights, t.flux_basis, t.rhs_cell, t.rhs_fct, t.hat_cell, t.hat_fct,
+            t.M, t.doftrafo, t.fct_normal_out, t.fct_dofs]
+    s = _Tables(t.k, t.ndofs, t.nd, t.ndf, t.nq, t.nqf, *[_p(a) for a in keep])
+    return s, keep
+
+
+def _prep(mesh, k, facet_type, flux_dg, rhs_dg, degree_dg):
+    flux_dg = np.ascontiguousarray(flux_dg, dtype=np.float64)
+    rhs_dg = np.ascontiguousarray(rhs_dg, dtype=np.float64)
+    nrhs = rhs_dg.shape[0]
+    t = make_tables(k, degree_dg)
+    assert flux_dg.shape == (nrhs, mesh.ncells * t.nd * 2), flux_dg.shape
+    assert rhs_dg.shape == (nrhs, mesh.ncells * t.nd)
+    facet_type = np.ascontiguousarray(facet_type, dtype=np.int8).reshape(nrhs, mesh.nfacets)
+    return t, nrhs, facet_type, flux_dg, rhs_dg
+
+
+def se_reconstruct(mesh, k, facet_type, flux_dg, rhs_dg, boundary_values=None, degree_dg=None,
+                   flux_hdiv=None, node_range=None):
+    """Run the reference algorithm over all (or a range of) patches; returns flux_hdiv
+    [nrhs, ncells*k(k+2)] (accumulated into `flux_hdiv` if given, like the reference)."""
+    lib = _load()
+    t, nrhs, facet_type, flux_dg, rhs_dg = _prep(mesh, k, facet_type, flux_dg, rhs_dg, degree_dg)
+    ms, keep_m = _mesh_struct(mesh)
+    ts, keep_t = _tables_struct(t)
+    if flux_hdiv is None:
+        flux_hdiv = np.zeros((nrhs, mesh.ncells * t.ndofs))
+    assert flux_hdiv.flags.c_contiguous and flux_hdiv.dtype == np.float64
+    if boundary_values is not None:
+        boundary_values = np.ascontiguousarray(boundary_values, dtype=np.float64)
+    nb, ne = node_range if node_range is not None else (0, mesh.nnodes)
+    st = lib.oracle_se_reconstruct(C.byref(ms), C.byref(ts), C.c_int(nrhs), _p(facet_type),
+                                   _p(boundary_values), _p(flux_dg), _p(rhs_dg), _p(flux_hdiv),
+                                   C.c_int32(nb), C.c_int32(ne))
+    if st == -1:
+        raise RuntimeError("Patch with only one cell")  # se/Patch.cpp:353-359
+    if st != 0:
+        raise RuntimeError(f"oracle failed with status {st}")
+    return flux_hdiv
+
+
+def se_patch(mesh, k, facet_type, flux_dg, rhs_dg, node, boundary_values=None, degree_dg=None):
+    """Single patch: returns (cells, sigma_tilde[nrhs,n,ndofs], patch_solution[nrhs,n,ndofs], u)."""
+    lib = _load()
+    t, nrhs, facet_type, flux_dg, rhs_dg = _prep(mesh, k, facet_type, flux_dg, rhs_dg, degree_dg)
+    ms, keep_m = _mesh_struct(mesh)
+    ts, keep_t = _tables_struct(t)
+    n = int(mesh.node_cells_offsets[node + 1] - mesh.node_cells_offsets[node])
+    nmax = int(np.diff(mesh.node_cells_offsets).max())
+    dim_max = 1 + (k - 1) * (nmax + 1) + (k - 1) * (k - 2) // 2 * nmax
+    st_ = np.zeros((nrhs, n, t.ndofs))
+    sol = np.zeros((nrhs, n, t.ndofs))
+    cells = np.zeros(n, dtype=np.int32)
+    u = np.zeros((nrhs, dim_max))
+    if boundary_values is not None:
+        boundary_values = np.ascontiguousarray(boundary_values, dtype=np.float64)
+    st = lib.oracle_se_patch(C.byref(ms), C.byref(ts), C.c_int(nrhs), _p(facet_type),
+                             _p(boundary_values), _p(flux_dg), _p(rhs_dg), C.c_int32(node),
+                             _p(st_), _p(sol), _p(cells), _p(u))
+    if st < 0:
+        raise RuntimeError(f"oracle failed with status {st}")
+    return cells, st_, sol, u
+
+
+def build_patches(mesh, facet_type, node_range=None):
+    """Patch fans of all nodes (see eqlb_oracle.h: oracle_build_patches)."""
+    lib = _load()
+    facet_type = np.ascontiguousarray(facet_type, dtype=np.int8).reshape(-1, mesh.nfacets)
+    nrhs = facet_type.shape[0]
+    ms, keep_m = _mesh_struct(mesh)
+    nb, ne = node_range if node_range is not None else (0, mesh.nnodes)
+    nn = ne - nb
+    stride = int(np.diff(mesh.node_cells_offsets).max()) + 2
+    ncells = np.zeros(nn, dtype=np.int32)
+    cells = np.zeros((nn, stride), dtype=np.int32)
+    fcts = np.zeros((nn, stride), dtype=np.int32)
+    fl = np.zeros((nn, 2 * stride), dtype=np.int8)
+    il = np.zeros((nn, stride), dtype=np.int8)
+    types = np.zeros((nn, nrhs), dtype=np.int8)
+    st = lib.oracle_build_patches(C.byref(ms), C.c_int(nrhs), _p(facet_type), C.c_int32(nb),
+                                  C.c_int32(ne), C.c_int32(stride), _p(ncells), _p(cells),
+                                  _p(fcts), _p(fl), _p(il), _p(types))
+    if st != 0:
+        raise RuntimeError(f"oracle failed with status {st}")
+    return dict(ncells=ncells, cells=cells, fcts=fcts, fcts_local=fl, inodes_local=il,
+                types=types, stride=stride)
