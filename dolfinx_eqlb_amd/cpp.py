@@ -1,0 +1,208 @@
+"""ctypes binding of libeqlb_amd.so (include/eqlb.h) - the stand-in for the reference's
+pybind11 module `dolfinx_eqlb.cpp` (python/dolfinx_eqlb/wrappers.cpp:259-272).
+
+The product path has no CPU fallback: if the HIP library is missing or no device is visible,
+the calls raise.  Errors of the C ABI are raised as RuntimeError, like the reference's
+std::runtime_error -> RuntimeError translation.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeqlb_amd.so")
+
+MEM_HOST, MEM_DEVICE = 0, 1
+SOLVER_LDS_CHOLESKY, SOLVER_SHUFFLE = 0, 1
+SCATTER_SLOTS, SCATTER_ATOMIC = 0, 1
+
+# every symbol include/eqlb.h declares (tests check that the library exports all of them)
+EXPORTED_SYMBOLS = [
+    "eqlb_last_error", "eqlb_device_count", "eqlb_mesh_create", "eqlb_mesh_destroy",
+    "eqlb_mesh_max_patch_cells", "eqlb_se_create", "eqlb_se_destroy", "eqlb_se_set_option",
+    "eqlb_se_set_boundary", "eqlb_se_equilibrate", "eqlb_se_num_patches",
+    "eqlb_se_export_patches", "eqlb_get_reference_table", "eqlb_se_last_kernel_ms",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libeqlb_amd.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()')")
+        L = C.CDLL(LIB_PATH)
+        L.eqlb_last_error.restype = C.c_char_p
+        L.eqlb_device_count.restype = C.c_int
+        L.eqlb_se_num_patches.restype = C.c_int64
+        L.eqlb_se_last_kernel_ms.restype = C.c_double
+        L.eqlb_mesh_max_patch_cells.restype = C.c_int32
+        for name in ("eqlb_mesh_destroy", "eqlb_se_destroy"):
+            getattr(L, name).restype = None
+        _lib = L
+    return _lib
+
+
+def _check(status):
+    if status != 0:
+        raise RuntimeError(lib().eqlb_last_error().decode() or f"eqlb error {status}")
+
+
+def _hp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count() -> int:
+    return int(lib().eqlb_device_count())
+
+
+class DeviceMesh:
+    """Device-resident copy of a flat mesh (eqlb_mesh_create)."""
+
+    def __init__(self, mesh):
+        self.mesh = mesh
+        self._h = C.c_void_p()
+        arrs = [np.ascontiguousarray(mesh.x, dtype=np.float64),
+                np.ascontiguousarray(mesh.cell_nodes, dtype=np.int32),
+                np.ascontiguousarray(mesh.cell_facets, dtype=np.int32),
+                np.ascontiguousarray(mesh.facet_nodes, dtype=np.int32),
+                np.ascontiguousarray(mesh.facet_cells_offsets, dtype=np.int32),
+                np.ascontiguousarray(mesh.facet_cells, dtype=np.int32),
+                np.ascontiguousarray(mesh.node_cells_offsets, dtype=np.int32),
+                np.ascontiguousarray(mesh.node_cells, dtype=np.int32),
+                np.ascontiguousarray(mesh.node_facets_offsets, dtype=np.int32),
+                np.ascontiguousarray(mesh.node_facets, dtype=np.int32),
+                np.ascontiguousarray(mesh.facet_perm, dtype=np.uint8)]
+        _check(lib().eqlb_mesh_create(C.c_int32(mesh.nnodes), C.c_int32(mesh.ncells),
+                                      C.c_int32(mesh.nfacets), *[_hp(a) for a in arrs],
+                                      C.byref(self._h)))
+
+    @property
+    def max_patch_cells(self):
+        return int(lib().eqlb_mesh_max_patch_cells(self._h))
+
+    def close(self):
+        if self._h:
+            lib().eqlb_mesh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SemiExplicitEquilibrator:
+    """eqlb_se_* handle: RT_k equilibrator on a device mesh."""
+
+    def __init__(self, dmesh: DeviceMesh, k: int, nrhs: int, degree_dg=None,
+                 reconstruct_stress=False, estimate_korn=False):
+        self.dmesh = dmesh
+        self.k, self.nrhs = k, nrhs
+        self.degree_dg = k - 1 if degree_dg is None else degree_dg
+        self.nrt = k * (k + 2)
+        self.nd = (self.degree_dg + 1) * (self.degree_dg + 2) // 2
+        self._h = C.c_void_p()
+        _check(lib().eqlb_se_create(dmesh._h, C.c_int32(k), C.c_int32(self.degree_dg),
+                                    C.c_int32(nrhs), C.c_int32(int(reconstruct_stress)),
+                                    C.c_int32(int(estimate_korn)), C.byref(self._h)))
+
+    def set_option(self, key: str, value: int):
+        _check(lib().eqlb_se_set_option(self._h, key.encode(), C.c_int32(value)))
+
+    def set_boundary(self, facet_type, boundary_values=None, node_mask=None):
+        m = self.dmesh.mesh
+        ft = np.ascontiguousarray(facet_type, dtype=np.int8).reshape(self.nrhs, m.nfacets)
+        bv = None
+        if boundary_values is not None:
+            bv = np.ascontiguousarray(boundary_values, dtype=np.float64)
+            assert bv.size == self.nrhs * m.ncells * self.nrt
+        nm = None
+        if node_mask is not None:
+            nm = np.ascontiguousarray(node_mask, dtype=np.uint8)
+            assert nm.size == m.nnodes
+        _check(lib().eqlb_se_set_boundary(self._h, _hp(ft), _hp(bv) if bv is not None else None,
+                                          _hp(nm) if nm is not None else None))
+
+    @property
+    def num_patches(self):
+        return int(lib().eqlb_se_num_patches(self._h))
+
+    def equilibrate_host(self, flux_dg, rhs_dg, flux_hdiv=None):
+        """Host numpy arrays in/out; flux_hdiv is accumulated (+=) like the reference."""
+        m = self.dmesh.mesh
+        g = np.ascontiguousarray(flux_dg, dtype=np.float64).reshape(self.nrhs, -1)
+        f = np.ascontiguousarray(rhs_dg, dtype=np.float64).reshape(self.nrhs, -1)
+        if g.shape[1] != m.ncells * self.nd * 2 or f.shape[1] != m.ncells * self.nd:
+            raise RuntimeError("Equilibration: Input sizes does not match")
+        if flux_hdiv is None:
+            flux_hdiv = np.zeros((self.nrhs, m.ncells * self.nrt))
+        assert flux_hdiv.dtype == np.float64 and flux_hdiv.flags.c_contiguous
+        assert flux_hdiv.size == self.nrhs * m.ncells * self.nrt
+        _check(lib().eqlb_se_equilibrate(self._h, _hp(g), _hp(f), _hp(flux_hdiv),
+                                         C.c_int32(MEM_HOST), None))
+        return flux_hdiv
+
+    def equilibrate_device(self, flux_dg_ptr: int, rhs_dg_ptr: int, flux_hdiv_ptr: int,
+                           stream: int = 0):
+        """Raw device pointers (e.g. torch tensor .data_ptr()) and a hipStream_t handle;
+        asynchronous."""
+        _check(lib().eqlb_se_equilibrate(self._h, C.c_void_p(flux_dg_ptr), C.c_void_p(rhs_dg_ptr),
+                                         C.c_void_p(flux_hdiv_ptr), C.c_int32(MEM_DEVICE),
+                                         C.c_void_p(stream)))
+
+    def last_kernel_ms(self, which=0):
+        return float(lib().eqlb_se_last_kernel_ms(self._h, C.c_int32(which)))
+
+    def export_patches(self):
+        m = self.dmesh.mesh
+        stride = self.dmesh.max_patch_cells + 2
+        nn = m.nnodes
+        out = dict(ncells=np.zeros(nn, np.int32), cells=np.zeros((nn, stride), np.int32),
+                   fcts=np.zeros((nn, stride), np.int32),
+                   fcts_local=np.zeros((nn, 2 * stride), np.int8),
+                   inodes_local=np.zeros((nn, stride), np.int8),
+                   reversed=np.zeros((nn, 2 * stride), np.int8), stride=stride)
+        _check(lib().eqlb_se_export_patches(self._h, C.c_int32(stride), _hp(out["ncells"]),
+                                            _hp(out["cells"]), _hp(out["fcts"]),
+                                            _hp(out["fcts_local"]), _hp(out["inodes_local"]),
+                                            _hp(out["reversed"])))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().eqlb_se_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def get_reference_table(k, degree_dg, name):
+    nrt, nd, nq = k * (k + 2), (degree_dg + 1) * (degree_dg + 2) // 2, k * (k + 1) // 2
+    shapes = {"S": (3, nrt, nrt), "F": (3, 3, nd, k), "H": (3, nd, nq), "D": (3, nd, 2, nq)}
+    out = np.zeros(shapes[name])
+    n = lib().eqlb_get_reference_table(C.c_int32(k), C.c_int32(degree_dg), name.encode(),
+                                       _hp(out), C.c_int32(out.size))
+    if n != out.size:
+        raise RuntimeError(lib().eqlb_last_error().decode())
+    return out
+
+
+def reconstruct_fluxes_semiexplt(flux_hdiv, flux_dg, rhs_dg, boundary_data, reconstruct_stress):
+    """Same name and argument order as the reference binding (wrappers.cpp:97-115); the
+    arguments are flat arrays [nrhs, ...] and `boundary_data` is a configured
+    SemiExplicitEquilibrator (it carries the facet types like base::BoundaryData does)."""
+    if reconstruct_stress:
+        raise RuntimeError("stress equilibration (weak symmetry) is not in this build")
+    return boundary_data.equilibrate_host(flux_dg, rhs_dg, flux_hdiv)

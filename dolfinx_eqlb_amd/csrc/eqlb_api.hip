@@ -1,0 +1,578 @@
+// Host side of the C ABI (include/eqlb.h): device residency of mesh / patch SoA, binning of
+// patches by size, kernel launches.  Mirrors the driver se::reconstruction<T>
+// (cpp/dolfinx_eqlb/se/reconstruction.hpp:337-407) with the per-call setup hoisted into the
+// handle.  There is NO CPU fallback: without a HIP device every compute entry point fails.
+#include "eqlb_internal.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace
+{
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+  do                                                                                              \
+  {                                                                                               \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(EQLB_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));                \
+  } while (0)
+
+template <typename T>
+int upload(T** dst, const T* src, size_t n)
+{
+  *dst = nullptr;
+  if (n == 0)
+    n = 1;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), n * sizeof(T)));
+  if (src)
+    HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+template <typename T>
+void dfree(T*& p)
+{
+  if (p)
+    (void)hipFree(p);
+  p = nullptr;
+}
+
+void free_boundary(eqlb_se* h)
+{
+  dfree(h->facet_type);
+  dfree(h->node_slot);
+  dfree(h->node_patch);
+  dfree(h->slot_cell);
+  dfree(h->slot_info);
+  dfree(h->pn);
+  dfree(h->pflag);
+  dfree(h->slots); // re-zeroed on the next call (node_mask may have changed)
+  h->boundary_set = false;
+}
+} // namespace
+
+extern "C" {
+
+const char* eqlb_last_error(void) { return g_error.c_str(); }
+
+int eqlb_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+int eqlb_mesh_create(int32_t nnodes, int32_t ncells, int32_t nfacets, const double* x,
+                     const int32_t* cell_nodes, const int32_t* cell_facets,
+                     const int32_t* facet_nodes, const int32_t* facet_cells_offsets,
+                     const int32_t* facet_cells, const int32_t* node_cells_offsets,
+                     const int32_t* node_cells, const int32_t* node_facets_offsets,
+                     const int32_t* node_facets, const uint8_t* facet_perm, eqlb_mesh_t** mesh)
+{
+  if (!mesh || nnodes <= 0 || ncells <= 0 || nfacets <= 0 || !x || !cell_nodes || !cell_facets
+      || !facet_nodes || !facet_cells_offsets || !facet_cells || !node_cells_offsets || !node_cells
+      || !node_facets_offsets || !node_facets || !facet_perm)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_mesh_create: null or empty input");
+  if (eqlb_device_count() < 1)
+    return fail(EQLB_ERR_DEVICE, "eqlb_mesh_create: no HIP device available");
+  (void)node_cells;
+  eqlb_mesh* m = new eqlb_mesh();
+  eqlb::DeviceMesh& d = m->m;
+  d.nnodes = nnodes;
+  d.ncells = ncells;
+  d.nfacets = nfacets;
+  d.h_node_ncells.resize(nnodes);
+  d.h_node_nfcts.resize(nnodes);
+  for (int32_t i = 0; i < nnodes; ++i)
+  {
+    d.h_node_ncells[i] = node_cells_offsets[i + 1] - node_cells_offsets[i];
+    d.h_node_nfcts[i] = node_facets_offsets[i + 1] - node_facets_offsets[i];
+    d.ncells_max = std::max(d.ncells_max, d.h_node_ncells[i]);
+  }
+  int st = 0;
+  st |= upload(&d.x, x, (size_t)nnodes * 3);
+  st |= upload(&d.cell_nodes, cell_nodes, (size_t)ncells * 3);
+  st |= upload(&d.cell_facets, cell_facets, (size_t)ncells * 3);
+  st |= upload(&d.facet_nodes, facet_nodes, (size_t)nfacets * 2);
+  st |= upload(&d.facet_cells_off, facet_cells_offsets, (size_t)nfacets + 1);
+  st |= upload(&d.facet_cells, facet_cells, (size_t)facet_cells_offsets[nfacets]);
+  st |= upload(&d.node_cells_off, node_cells_offsets, (size_t)nnodes + 1);
+  st |= upload(&d.node_facets_off, node_facets_offsets, (size_t)nnodes + 1);
+  st |= upload(&d.node_facets, node_facets, (size_t)node_facets_offsets[nnodes]);
+  st |= upload(&d.facet_perm, facet_perm, (size_t)ncells * 3);
+  st |= upload<double>(&d.cellJ, nullptr, (size_t)ncells * 4);
+  if (st)
+  {
+    eqlb_mesh_destroy(m);
+    return EQLB_ERR_DEVICE;
+  }
+  eqlb::launch_cell_geometry(ncells, d.x, d.cell_nodes, d.cellJ, nullptr);
+  if (hipDeviceSynchronize() != hipSuccess)
+  {
+    eqlb_mesh_destroy(m);
+    return fail(EQLB_ERR_DEVICE, "eqlb_mesh_create: geometry kernel failed");
+  }
+  *mesh = m;
+  return EQLB_OK;
+}
+
+void eqlb_mesh_destroy(eqlb_mesh_t* m)
+{
+  if (!m)
+    return;
+  eqlb::DeviceMesh& d = m->m;
+  dfree(d.x);
+  dfree(d.cellJ);
+  dfree(d.cell_nodes);
+  dfree(d.cell_facets);
+  dfree(d.facet_nodes);
+  dfree(d.facet_cells_off);
+  dfree(d.facet_cells);
+  dfree(d.node_cells_off);
+  dfree(d.node_facets_off);
+  dfree(d.node_facets);
+  dfree(d.facet_perm);
+  delete m;
+}
+
+int32_t eqlb_mesh_max_patch_cells(const eqlb_mesh_t* mesh) { return mesh ? mesh->m.ncells_max : 0; }
+
+int eqlb_se_create(eqlb_mesh_t* mesh, int32_t k, int32_t degree_dg, int32_t nrhs,
+                   int32_t reconstruct_stress, int32_t estimate_korn, eqlb_se_t** handle)
+{
+  if (!mesh || !handle || nrhs < 1)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "Equilibration: Input sizes does not match");
+  if (k < 1)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "Degree must be at least 1");
+  // se/reconstruction.hpp:363-373
+  if (degree_dg > k - 1 || degree_dg < 0)
+    return fail(EQLB_ERR_INVALID_ARGUMENT,
+                "Equilibration: Wrong polynomial degree of the projected RHS");
+  if (reconstruct_stress)
+  {
+    // se/reconstruction.hpp:376-388
+    if (nrhs < 2)
+      return fail(EQLB_ERR_INVALID_ARGUMENT,
+                  "Stress equilibration: Specify all rows of stress tensor");
+    if (k < 2)
+      return fail(EQLB_ERR_INVALID_ARGUMENT, "Stress equilibration: RT_k with k>1 required!");
+    return fail(EQLB_ERR_UNSUPPORTED, "stress equilibration (weak symmetry) is not in this build");
+  }
+  if (estimate_korn)
+    return fail(EQLB_ERR_UNSUPPORTED, "Korn constant estimation is not in this build");
+  std::vector<double> tab;
+  if (eqlb::fill_tables_host(k, degree_dg, tab) != 0 || degree_dg != k - 1 || k > 3)
+    return fail(EQLB_ERR_UNSUPPORTED, "RT_%d with DG_%d data is not in this build", k, degree_dg);
+  eqlb_se* h = new eqlb_se();
+  h->mesh = mesh;
+  h->k = k;
+  h->deg = degree_dg;
+  h->nrhs = nrhs;
+  h->nrt = k * (k + 2);
+  h->nd = (degree_dg + 1) * (degree_dg + 2) / 2;
+  int st = upload(&h->tables, tab.data(), tab.size());
+  st |= upload<int32_t>(&h->status, nullptr, 1);
+  if (st)
+  {
+    eqlb_se_destroy(h);
+    return EQLB_ERR_DEVICE;
+  }
+  (void)hipMemset(h->status, 0, sizeof(int32_t));
+  *handle = h;
+  return EQLB_OK;
+}
+
+void eqlb_se_destroy(eqlb_se_t* h)
+{
+  if (!h)
+    return;
+  free_boundary(h);
+  dfree(h->tables);
+  dfree(h->slots);
+  dfree(h->status);
+  dfree(h->d_flux_dg);
+  dfree(h->d_rhs_dg);
+  dfree(h->d_flux_hdiv);
+  for (auto& e : h->ev)
+    if (e)
+      (void)hipEventDestroy(e);
+  delete h;
+}
+
+int eqlb_se_set_option(eqlb_se_t* h, const char* key, int32_t value)
+{
+  if (!h || !key)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_set_option: null argument");
+  if (!strcmp(key, "solver"))
+  {
+    if (value != EQLB_SOLVER_LDS_CHOLESKY && value != EQLB_SOLVER_SHUFFLE)
+      return fail(EQLB_ERR_INVALID_ARGUMENT, "unknown solver %d", value);
+    h->solver = value;
+  }
+  else if (!strcmp(key, "scatter"))
+  {
+    if (value != EQLB_SCATTER_SLOTS && value != EQLB_SCATTER_ATOMIC)
+      return fail(EQLB_ERR_INVALID_ARGUMENT, "unknown scatter mode %d", value);
+    h->scatter = value;
+  }
+  else if (!strcmp(key, "timing"))
+    h->timing = value;
+  else
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "unknown option '%s'", key);
+  return EQLB_OK;
+}
+
+int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* boundary_values,
+                         const uint8_t* node_mask)
+{
+  if (!h || !facet_type)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_set_boundary: null argument");
+  const eqlb::DeviceMesh& m = h->mesh->m;
+  if (boundary_values)
+  {
+    const size_t nb = (size_t)h->nrhs * m.ncells * h->nrt;
+    for (size_t i = 0; i < nb; ++i)
+      if (boundary_values[i] != 0.0)
+        return fail(EQLB_ERR_UNSUPPORTED,
+                    "inhomogeneous flux boundary values are not in this build");
+  }
+  // OrientedPatch::set_max_patch_size (se/Patch.cpp:337-404): every local node is checked
+  for (int32_t i = 0; i < m.nnodes; ++i)
+  {
+    if (m.h_node_ncells[i] == 1)
+      return fail(EQLB_ERR_PATCH_TOO_SMALL, "Patch around node %d has only 1 cells.", i);
+    if (m.h_node_ncells[i] < 1)
+      return fail(EQLB_ERR_INVALID_ARGUMENT, "node %d belongs to no cell", i);
+  }
+  free_boundary(h);
+
+  // bins by lanes per patch: P = smallest of {4,8,16,32,64} >= number of patch facets
+  std::vector<int64_t> node_slot(m.nnodes, -1), node_patch(m.nnodes, -1);
+  int64_t count[eqlb::MAX_BINS] = {0, 0, 0, 0, 0};
+  std::vector<int8_t> node_bin(m.nnodes, -1);
+  for (int32_t i = 0; i < m.nnodes; ++i)
+  {
+    if (node_mask && !node_mask[i])
+      continue;
+    const int nf = m.h_node_nfcts[i];
+    int b = 0;
+    while (b < eqlb::MAX_BINS && eqlb::BIN_P[b] < nf)
+      ++b;
+    if (b == eqlb::MAX_BINS || m.h_node_ncells[i] > 63)
+      return fail(EQLB_ERR_PATCH_TOO_LARGE, "Patch around node %d has %d cells (limit 63)", i,
+                  m.h_node_ncells[i]);
+    node_bin[i] = (int8_t)b;
+    ++count[b];
+  }
+  int64_t slot_off = 0, patch_off = 0;
+  for (int b = 0; b < eqlb::MAX_BINS; ++b)
+  {
+    h->bins[b].P = eqlb::BIN_P[b];
+    h->bins[b].npatch = count[b];
+    h->bins[b].slot_offset = slot_off;
+    h->bins[b].patch_offset = patch_off;
+    slot_off += count[b] * eqlb::BIN_P[b];
+    patch_off += count[b];
+    count[b] = 0;
+  }
+  h->nslots = slot_off;
+  h->npatch_total = patch_off;
+  for (int32_t i = 0; i < m.nnodes; ++i)
+  {
+    const int b = node_bin[i];
+    if (b < 0)
+      continue;
+    node_patch[i] = h->bins[b].patch_offset + count[b];
+    node_slot[i] = h->bins[b].slot_offset + count[b] * eqlb::BIN_P[b];
+    ++count[b];
+  }
+
+  int st = 0;
+  st |= upload(&h->facet_type, facet_type, (size_t)h->nrhs * m.nfacets);
+  st |= upload(&h->node_slot, node_slot.data(), (size_t)m.nnodes);
+  st |= upload(&h->node_patch, node_patch.data(), (size_t)m.nnodes);
+  st |= upload<int32_t>(&h->slot_cell, nullptr, (size_t)h->nslots);
+  st |= upload<uint32_t>(&h->slot_info, nullptr, (size_t)h->nslots);
+  st |= upload<uint8_t>(&h->pn, nullptr, (size_t)h->npatch_total);
+  st |= upload<uint8_t>(&h->pflag, nullptr, (size_t)h->npatch_total * h->nrhs);
+  if (st)
+    return EQLB_ERR_DEVICE;
+  HIP_TRY(hipMemset(h->slot_cell, 0xff, sizeof(int32_t) * std::max<int64_t>(h->nslots, 1)));
+  HIP_TRY(hipMemset(h->slot_info, 0, sizeof(uint32_t) * std::max<int64_t>(h->nslots, 1)));
+
+  eqlb::BuildArgs a{};
+  a.nnodes = m.nnodes;
+  a.nfacets = m.nfacets;
+  a.nrhs = h->nrhs;
+  a.cell_nodes = m.cell_nodes;
+  a.cell_facets = m.cell_facets;
+  a.facet_nodes = m.facet_nodes;
+  a.facet_cells_off = m.facet_cells_off;
+  a.facet_cells = m.facet_cells;
+  a.node_cells_off = m.node_cells_off;
+  a.node_facets_off = m.node_facets_off;
+  a.node_facets = m.node_facets;
+  a.facet_perm = m.facet_perm;
+  a.facet_type = h->facet_type;
+  a.node_slot = h->node_slot;
+  a.node_patch = h->node_patch;
+  a.npatch_total = h->npatch_total;
+  a.slot_cell = h->slot_cell;
+  a.slot_info = h->slot_info;
+  a.pn = h->pn;
+  a.pflag = h->pflag;
+  a.stride = 0;
+  eqlb::launch_build_patches(a, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  h->boundary_set = true;
+  return EQLB_OK;
+}
+
+int64_t eqlb_se_num_patches(const eqlb_se_t* h) { return h ? h->npatch_total : 0; }
+
+int eqlb_se_export_patches(eqlb_se_t* h, int32_t stride, int32_t* ncells, int32_t* cells,
+                           int32_t* fcts, int8_t* fcts_local, int8_t* inodes_local,
+                           int8_t* reversed)
+{
+  if (!h || !ncells || !cells || !fcts || !fcts_local || !inodes_local || !reversed)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_export_patches: null argument");
+  if (!h->boundary_set)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_export_patches: set the boundary first");
+  const eqlb::DeviceMesh& m = h->mesh->m;
+  if (stride < m.ncells_max + 2)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_export_patches: stride too small");
+  const size_t nn = (size_t)m.nnodes;
+  int32_t *d_n = nullptr, *d_c = nullptr, *d_f = nullptr;
+  int8_t *d_fl = nullptr, *d_il = nullptr, *d_rv = nullptr;
+  int st = 0;
+  st |= upload<int32_t>(&d_n, nullptr, nn);
+  st |= upload<int32_t>(&d_c, nullptr, nn * stride);
+  st |= upload<int32_t>(&d_f, nullptr, nn * stride);
+  st |= upload<int8_t>(&d_fl, nullptr, nn * stride * 2);
+  st |= upload<int8_t>(&d_il, nullptr, nn * stride);
+  st |= upload<int8_t>(&d_rv, nullptr, nn * stride * 2);
+  if (!st)
+  {
+    eqlb::BuildArgs a{};
+    a.nnodes = m.nnodes;
+    a.nfacets = m.nfacets;
+    a.nrhs = h->nrhs;
+    a.cell_nodes = m.cell_nodes;
+    a.cell_facets = m.cell_facets;
+    a.facet_nodes = m.facet_nodes;
+    a.facet_cells_off = m.facet_cells_off;
+    a.facet_cells = m.facet_cells;
+    a.node_cells_off = m.node_cells_off;
+    a.node_facets_off = m.node_facets_off;
+    a.node_facets = m.node_facets;
+    a.facet_perm = m.facet_perm;
+    a.facet_type = h->facet_type;
+    a.node_slot = nullptr;
+    a.node_patch = nullptr;
+    a.npatch_total = 0;
+    a.stride = stride;
+    a.ex_ncells = d_n;
+    a.ex_cells = d_c;
+    a.ex_fcts = d_f;
+    a.ex_fl = d_fl;
+    a.ex_il = d_il;
+    a.ex_rev = d_rv;
+    eqlb::launch_build_patches(a, nullptr);
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess)
+      e = hipMemcpy(ncells, d_n, nn * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+      e = hipMemcpy(cells, d_c, nn * stride * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+      e = hipMemcpy(fcts, d_f, nn * stride * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+      e = hipMemcpy(fcts_local, d_fl, nn * stride * 2, hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+      e = hipMemcpy(inodes_local, d_il, nn * stride, hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+      e = hipMemcpy(reversed, d_rv, nn * stride * 2, hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+      st = fail(EQLB_ERR_DEVICE, "eqlb_se_export_patches: %s", hipGetErrorString(e));
+  }
+  dfree(d_n);
+  dfree(d_c);
+  dfree(d_f);
+  dfree(d_fl);
+  dfree(d_il);
+  dfree(d_rv);
+  return st ? EQLB_ERR_DEVICE : EQLB_OK;
+}
+
+int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_dg,
+                        double* flux_hdiv, int32_t memspace, void* stream_)
+{
+  if (!h || !flux_dg || !rhs_dg || !flux_hdiv)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "Equilibration: Input sizes does not match");
+  if (!h->boundary_set)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_equilibrate: boundary data not set");
+  const eqlb::DeviceMesh& m = h->mesh->m;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const size_t n_g = (size_t)h->nrhs * m.ncells * h->nd * 2;
+  const size_t n_f = (size_t)h->nrhs * m.ncells * h->nd;
+  const size_t n_x = (size_t)h->nrhs * m.ncells * h->nrt;
+
+  const double *d_g = flux_dg, *d_f = rhs_dg;
+  double* d_x = flux_hdiv;
+  if (memspace == EQLB_MEM_HOST)
+  {
+    if (!h->d_flux_dg)
+    {
+      if (upload<double>(&h->d_flux_dg, nullptr, n_g) || upload<double>(&h->d_rhs_dg, nullptr, n_f)
+          || upload<double>(&h->d_flux_hdiv, nullptr, n_x))
+        return EQLB_ERR_DEVICE;
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_flux_dg, flux_dg, n_g * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(h->d_rhs_dg, rhs_dg, n_f * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(h->d_flux_hdiv, flux_hdiv, n_x * sizeof(double), hipMemcpyHostToDevice, stream));
+    d_g = h->d_flux_dg;
+    d_f = h->d_rhs_dg;
+    d_x = h->d_flux_hdiv;
+  }
+  else if (memspace != EQLB_MEM_DEVICE)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_equilibrate: unknown memory space");
+
+  if (h->scatter == EQLB_SCATTER_SLOTS && !h->slots)
+  {
+    if (upload<double>(&h->slots, nullptr, n_x * 3))
+      return EQLB_ERR_DEVICE;
+    // slots of (cell, vertex) pairs whose node is not equilibrated (node_mask) stay zero
+    HIP_TRY(hipMemset(h->slots, 0, n_x * 3 * sizeof(double)));
+  }
+  if (h->timing && !h->ev[0])
+    for (auto& e : h->ev)
+      HIP_TRY(hipEventCreate(&e));
+
+  eqlb::SeArgs a{};
+  a.cellJ = m.cellJ;
+  a.slot_cell = h->slot_cell;
+  a.slot_info = h->slot_info;
+  a.pn = h->pn;
+  a.pflag = h->pflag;
+  a.tables = h->tables;
+  a.flux_dg = d_g;
+  a.rhs_dg = d_f;
+  a.out = (h->scatter == EQLB_SCATTER_SLOTS) ? h->slots : d_x;
+  a.status = h->status;
+  a.npatch_total = h->npatch_total;
+  a.ncells = m.ncells;
+  a.nrhs = h->nrhs;
+
+  if (h->timing)
+    HIP_TRY(hipEventRecord(h->ev[0], stream));
+  h->n_patch_launches = 0;
+  for (int b = 0; b < eqlb::MAX_BINS; ++b)
+  {
+    if (h->bins[b].npatch == 0)
+      continue;
+    a.npatch = h->bins[b].npatch;
+    a.slot_offset = h->bins[b].slot_offset;
+    a.patch_offset = h->bins[b].patch_offset;
+    const int st = eqlb::launch_se_patch(h->k, h->deg, h->bins[b].P, h->solver, h->scatter, a, stream);
+    if (st)
+      return fail(st, "patch kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
+    ++h->n_patch_launches;
+  }
+  if (h->timing)
+    HIP_TRY(hipEventRecord(h->ev[1], stream));
+  if (h->scatter == EQLB_SCATTER_SLOTS)
+    eqlb::launch_reduce_slots(h->nrt, m.ncells, h->nrhs, h->slots, d_x, stream);
+  if (h->timing)
+  {
+    HIP_TRY(hipEventRecord(h->ev[2], stream));
+    h->ev_valid = true;
+  }
+  HIP_TRY(hipGetLastError());
+
+  if (memspace == EQLB_MEM_HOST)
+  {
+    HIP_TRY(hipMemcpyAsync(flux_hdiv, d_x, n_x * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    int32_t status = 0;
+    HIP_TRY(hipMemcpy(&status, h->status, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (status)
+    {
+      (void)hipMemset(h->status, 0, sizeof(int32_t));
+      return fail(EQLB_ERR_SINGULAR, "patch system not positive definite");
+    }
+  }
+  return EQLB_OK;
+}
+
+double eqlb_se_last_kernel_ms(const eqlb_se_t* h, int32_t which)
+{
+  if (!h || !h->ev_valid)
+    return 0.0;
+  float ms = 0.f;
+  if (hipEventSynchronize(h->ev[2]) != hipSuccess)
+    return 0.0;
+  hipError_t e = hipSuccess;
+  if (which == 0) // patch kernels (all bins)
+    e = hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
+  else if (which == 1) // slot reduction
+    e = hipEventElapsedTime(&ms, h->ev[1], h->ev[2]);
+  else
+    e = hipEventElapsedTime(&ms, h->ev[0], h->ev[2]);
+  return (e == hipSuccess) ? (double)ms : 0.0;
+}
+
+int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, double* out,
+                             int32_t capacity)
+{
+  std::vector<double> tab;
+  if (!name || !out || eqlb::fill_tables_host(k, degree_dg, tab) != 0)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_get_reference_table: unknown table");
+  const int nrt = k * (k + 2), nd = (degree_dg + 1) * (degree_dg + 2) / 2, nq = k * (k + 1) / 2;
+  const size_t nS = (size_t)3 * nrt * nrt, nF = (size_t)9 * nd * k, nH = (size_t)3 * nd * nq,
+               nD = (size_t)6 * nd * nq;
+  size_t off = 0, len = 0;
+  if (!strcmp(name, "S"))
+  {
+    off = 0;
+    len = nS;
+  }
+  else if (!strcmp(name, "F"))
+  {
+    off = nS;
+    len = nF;
+  }
+  else if (!strcmp(name, "H"))
+  {
+    off = nS + nF;
+    len = nH;
+  }
+  else if (!strcmp(name, "D"))
+  {
+    off = nS + nF + nH;
+    len = nD;
+  }
+  else
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_get_reference_table: unknown table '%s'", name);
+  if ((size_t)capacity < len)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_get_reference_table: capacity too small");
+  std::copy(tab.begin() + off, tab.begin() + off + len, out);
+  return (int)len;
+}
+
+} // extern "C"

@@ -1,0 +1,133 @@
+// Internal structures shared by the host API and the HIP kernels of libeqlb_amd.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/eqlb.h"
+
+namespace eqlb
+{
+
+// Packed per-(patch, cell) descriptor, one uint32 per lane slot (lane-contiguous SoA):
+//   bits 0-1 fm  local id of E_{a-1} on T_a      bits 2-3 fp  local id of E_a on T_a
+//   bits 4-5 ln  local id of the patch node      bit 6 rev_m  E_{a-1} reversed w.r.t. T_{a-1}
+//   bit 7 rev_p  E_a reversed w.r.t. T_{a+1}
+constexpr uint32_t INFO_FM_SHIFT = 0, INFO_FP_SHIFT = 2, INFO_LN_SHIFT = 4;
+constexpr uint32_t INFO_REV_M = 1u << 6, INFO_REV_P = 1u << 7;
+
+// per-(rhs, patch) flags
+constexpr uint8_t PFLAG_INTERIOR = 1, PFLAG_BC0 = 2, PFLAG_BCN = 4;
+
+constexpr int MAX_BINS = 5;          // lanes per patch P = 4, 8, 16, 32, 64
+constexpr int BIN_P[MAX_BINS] = {4, 8, 16, 32, 64};
+
+struct DeviceMesh
+{
+  int32_t nnodes = 0, ncells = 0, nfacets = 0, ncells_max = 0;
+  // device arrays
+  double* x = nullptr;            // [nnodes][3]
+  double* cellJ = nullptr;        // [ncells][4] J00 J01 J10 J11 (dx_i/dX_j), cached affine maps
+  int32_t *cell_nodes = nullptr, *cell_facets = nullptr, *facet_nodes = nullptr;
+  int32_t *facet_cells_off = nullptr, *facet_cells = nullptr;
+  int32_t *node_cells_off = nullptr, *node_facets_off = nullptr, *node_facets = nullptr;
+  uint8_t* facet_perm = nullptr;
+  // host copies needed for binning
+  std::vector<int32_t> h_node_ncells, h_node_nfcts;
+};
+
+struct Bin
+{
+  int P = 0;
+  int64_t npatch = 0;
+  int64_t slot_offset = 0;   // into slot arrays
+  int64_t patch_offset = 0;  // into patch arrays
+};
+
+// kernel arguments of the patch kernel (one launch per bin)
+struct SeArgs
+{
+  const double* cellJ;
+  const int32_t* slot_cell;   // [nslots] global cell id or -1
+  const uint32_t* slot_info;  // [nslots]
+  const uint8_t* pn;          // [npatch] cells per patch
+  const uint8_t* pflag;       // [nrhs][npatch_total]
+  const double* tables;       // S | F | H | D
+  const double* flux_dg;      // [nrhs][ncells*ND*2]
+  const double* rhs_dg;       // [nrhs][ncells*ND]
+  double* out;                // slots [nrhs][ncells][3][NRT] or flux_hdiv [nrhs][ncells*NRT]
+  int32_t* status;            // device error flag
+  int64_t npatch;             // patches of this bin
+  int64_t slot_offset, patch_offset, npatch_total;
+  int32_t ncells, nrhs;
+};
+
+struct BuildArgs
+{
+  int32_t nnodes, nfacets, nrhs;
+  const int32_t *cell_nodes, *cell_facets, *facet_nodes, *facet_cells_off, *facet_cells;
+  const int32_t *node_cells_off, *node_facets_off, *node_facets;
+  const uint8_t* facet_perm;
+  const int8_t* facet_type;  // [nrhs][nfacets]
+  const int64_t* node_slot;  // first lane slot of the node's patch, -1: not equilibrated
+  const int64_t* node_patch; // patch index
+  int64_t npatch_total;
+  int32_t* slot_cell;
+  uint32_t* slot_info;
+  uint8_t* pn;
+  uint8_t* pflag;
+  // optional export in OrientedPatch layout (nullptr: off)
+  int32_t stride;
+  int32_t *ex_ncells, *ex_cells, *ex_fcts;
+  int8_t *ex_fl, *ex_il, *ex_rev;
+};
+
+void launch_build_patches(const BuildArgs& a, hipStream_t stream);
+void launch_cell_geometry(int32_t ncells, const double* x, const int32_t* cell_nodes,
+                          double* cellJ, hipStream_t stream);
+// returns 0 or EQLB_ERR_UNSUPPORTED
+int launch_se_patch(int k, int deg, int P, int solver, int scatter, const SeArgs& a,
+                    hipStream_t stream);
+void launch_reduce_slots(int nrt, int32_t ncells, int32_t nrhs, const double* slots, double* x,
+                         hipStream_t stream);
+size_t table_doubles(int k, int deg);
+int fill_tables_host(int k, int deg, std::vector<double>& out);
+
+} // namespace eqlb
+
+struct eqlb_mesh
+{
+  eqlb::DeviceMesh m;
+};
+
+struct eqlb_se
+{
+  eqlb_mesh* mesh = nullptr;
+  int k = 0, deg = 0, nrhs = 0;
+  int nrt = 0, nd = 0;
+  int solver = EQLB_SOLVER_LDS_CHOLESKY, scatter = EQLB_SCATTER_SLOTS, timing = 0;
+  bool boundary_set = false;
+  int64_t npatch_total = 0, nslots = 0;
+  eqlb::Bin bins[eqlb::MAX_BINS];
+  // device
+  double* tables = nullptr;
+  int8_t* facet_type = nullptr;     // [nrhs][nfacets]
+  int64_t* node_slot = nullptr;     // [nnodes] first slot of the node's patch or -1
+  int64_t* node_patch = nullptr;    // [nnodes] patch index or -1
+  int32_t* node_P = nullptr;        // [nnodes] lanes per patch
+  int32_t* slot_cell = nullptr;
+  uint32_t* slot_info = nullptr;
+  uint8_t* pn = nullptr;
+  uint8_t* pflag = nullptr;
+  double* slots = nullptr;          // [nrhs][ncells][3][nrt]
+  int32_t* status = nullptr;
+  // staging for host-memory calls
+  double *d_flux_dg = nullptr, *d_rhs_dg = nullptr, *d_flux_hdiv = nullptr;
+  // timing
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool ev_valid = false;
+  int n_patch_launches = 0;
+};

@@ -1,0 +1,88 @@
+"""Flux equilibration based on a semi-explicit strategy - host-side mirror of the reference's
+`FluxEqlbSE` (python/dolfinx_eqlb/eqlb/FluxEqlbSE.py:26-198) on flat arrays.
+
+Same constructor arguments, methods and error behaviour; DOLFINx Functions are replaced by
+numpy arrays in the layouts of include/eqlb.h (the DOLFINx adapter a maintainer would write is
+shown in INTEGRATION.md).  All numerical work happens in libeqlb_amd.so on the GPU.
+"""
+
+import typing
+
+import numpy as np
+
+from .. import cpp
+from ..mesh import Mesh
+
+
+class fluxbc:
+    """Homogeneous flux boundary condition on a set of facets (stand-in for
+    python/dolfinx_eqlb/eqlb/bcs.py:25 `fluxbc`; inhomogeneous data is a 'next' row)."""
+
+    def __init__(self, value, facets, V=None, requires_projection=False, quadrature_degree=None):
+        if value not in (0, 0.0, None):
+            raise NotImplementedError("inhomogeneous flux BCs are not in this build")
+        self.facets = np.asarray(facets, dtype=np.int32)
+
+
+class FluxEqlbSE:
+    """Equilibrate fluxes in a semi-explicit manner (steps 1 and 2 of the reference class)."""
+
+    def __init__(self, degree_flux: int, msh: Mesh, list_rhs: typing.List[np.ndarray],
+                 list_proj_flux: typing.List[np.ndarray],
+                 equilibrate_stress: typing.Optional[bool] = False,
+                 estimate_korn_constant: typing.Optional[bool] = False,
+                 device_mesh: typing.Optional[cpp.DeviceMesh] = None):
+        self.degree_flux = degree_flux
+        self.n_fluxes = len(list_rhs)
+        self.equilibrate_stresses = equilibrate_stress
+        self.estimate_korn_constant = estimate_korn_constant
+        self.korn_constants = None
+        if len(list_proj_flux) != self.n_fluxes:
+            raise RuntimeError("Mismatching inputs!")  # FluxEqlbSE.py:74-75
+        self.mesh = msh
+        self.list_rhs = [np.ascontiguousarray(r, dtype=np.float64).ravel() for r in list_rhs]
+        self.list_proj_flux = [np.ascontiguousarray(g, dtype=np.float64).ravel()
+                               for g in list_proj_flux]
+        nd = self.list_rhs[0].size // msh.ncells
+        degree_dg = {1: 0, 3: 1, 6: 2, 10: 3}.get(nd)
+        if degree_dg is None or nd * msh.ncells != self.list_rhs[0].size:
+            raise RuntimeError("Equilibration: Input sizes does not match")
+        self.degree_dg = degree_dg
+        self.device_mesh = device_mesh if device_mesh is not None else cpp.DeviceMesh(msh)
+        self._eq = cpp.SemiExplicitEquilibrator(self.device_mesh, degree_flux, self.n_fluxes,
+                                                degree_dg, equilibrate_stress,
+                                                estimate_korn_constant)
+        ndofs = degree_flux * (degree_flux + 2)
+        self.list_flux = np.zeros((self.n_fluxes, msh.ncells * ndofs))
+        self.boundary_data = None
+
+    def set_boundary_conditions(self, list_bfct_prime: typing.List[np.ndarray],
+                                list_bcs_flux: typing.List[typing.List[fluxbc]]):
+        """list_bfct_prime[i]: facets with essential BCs of the primal problem;
+        list_bcs_flux[i]: flux BCs (FluxEqlbSE.py:118-147)."""
+        if self.n_fluxes != len(list_bfct_prime) or self.n_fluxes != len(list_bcs_flux):
+            raise RuntimeError("Mismatching inputs!")
+        ft = np.zeros((self.n_fluxes, self.mesh.nfacets), dtype=np.int8)
+        for i in range(self.n_fluxes):
+            ft[i, np.asarray(list_bfct_prime[i], dtype=np.int64)] = 1
+            for bc in list_bcs_flux[i]:
+                ft[i, bc.facets] = 2
+        self.facet_type = ft
+        self._eq.set_boundary(ft)
+        self.boundary_data = self._eq
+
+    def equilibrate_fluxes(self):
+        """Equilibrate the fluxes (accumulates into list_flux like the reference)."""
+        if self.boundary_data is None:
+            raise RuntimeError("Boundary conditions have not been set")
+        cpp.reconstruct_fluxes_semiexplt(self.list_flux, np.stack(self.list_proj_flux),
+                                         np.stack(self.list_rhs), self.boundary_data,
+                                         self.equilibrate_stresses)
+
+    def get_reconstructed_fluxes(self, subproblem: int):
+        """(corrector in discontinuous hierarchic RT_k, projected flux in DG_{k-1}^2): the
+        reconstructed flux is their sum (FluxEqlbSE.py:176-186)."""
+        return self.list_flux[subproblem], self.list_proj_flux[subproblem]
+
+    def get_korn_constants(self):
+        raise RuntimeError("Korn constants are not estimated!")

@@ -1,0 +1,171 @@
+/*
+ * eqlb.h - C ABI of the MI355X-native patch-local flux equilibrator (libeqlb_amd.so).
+ *
+ * Drop-in boundary for the semi-explicit equilibration hot path of dolfinx_eqlb v1.2.0.
+ * The reference exposes this path through pybind11 on DOLFINx objects
+ * (python/dolfinx_eqlb/wrappers.cpp:97-137 `reconstruct_fluxes_semiexplt[_with_kornconst]`,
+ * driver cpp/dolfinx_eqlb/se/reconstruction.hpp:337-407); here the same call takes the flat
+ * arrays those objects hold.  Every entry point cites the reference interface it replaces.
+ * INTEGRATION.md shows the pybind11/DOLFINx-side adapter a maintainer would add.
+ *
+ * Conventions: all floating point is fp64, indices int32, flags int8/uint8.  Functions return
+ * 0 on success and a negative EQLB_ERR_* code otherwise (the reference throws
+ * std::runtime_error -> Python RuntimeError); eqlb_last_error() gives the message of the last
+ * failure on the calling thread.  One handle per host thread / HIP stream; not re-entrant
+ * (like the reference, se/reconstruction.hpp:275-283 shared scratch).
+ */
+#ifndef EQLB_H
+#define EQLB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EQLB_OK 0
+#define EQLB_ERR_INVALID_ARGUMENT (-1) /* size / degree mismatch, se/reconstruction.hpp:358-388 */
+#define EQLB_ERR_PATCH_TOO_SMALL (-2)  /* patch with one cell, se/Patch.cpp:353-359 */
+#define EQLB_ERR_UNSUPPORTED (-3)      /* configuration outside this build */
+#define EQLB_ERR_DEVICE (-4)           /* HIP runtime failure / no device */
+#define EQLB_ERR_PATCH_TOO_LARGE (-5)  /* patch with more than 63 cells (one wavefront per patch) */
+#define EQLB_ERR_SINGULAR (-6)         /* patch system not positive definite (incompatible data) */
+
+/* memory space of the data pointers handed to eqlb_se_equilibrate */
+#define EQLB_MEM_HOST 0
+#define EQLB_MEM_DEVICE 1
+
+/* facet types = base::PatchFacetType, cpp/dolfinx_eqlb/base/Patch.hpp:22-27 */
+#define EQLB_FACET_INTERNAL 0
+#define EQLB_FACET_ESSNT_PRIMAL 1
+#define EQLB_FACET_ESSNT_DUAL 2
+
+/* variants of the patch kernel (eqlb_se_set_option, key "solver" / "scatter") */
+#define EQLB_SOLVER_LDS_CHOLESKY 0 /* dense Cholesky of the patch tile in LDS */
+#define EQLB_SOLVER_SHUFFLE 1      /* block-tridiagonal elimination in registers, wave shuffles */
+#define EQLB_SCATTER_SLOTS 0       /* per-(cell, vertex) slots + deterministic reduction */
+#define EQLB_SCATTER_ATOMIC 1      /* fp64 global atomic add into the RT coefficient vector */
+
+typedef struct eqlb_mesh eqlb_mesh_t;
+typedef struct eqlb_se eqlb_se_t;
+
+/* Message of the last error on this thread ("" if none). */
+const char* eqlb_last_error(void);
+
+/* Number of HIP devices visible (0 if none / runtime unavailable). */
+int eqlb_device_count(void);
+
+/*
+ * Mesh topology/geometry, copied to the current HIP device.  Replaces what the reference reads
+ * from dolfinx::mesh::Mesh after FluxEquilibrator.initialise_mesh_info
+ * (python/dolfinx_eqlb/eqlb/FluxEquilibrator.py:52-67; se/Patch.cpp:20-26 connectivities,
+ * se/reconstruction.hpp:83-84 facet permutations):
+ *   x            [nnodes][3]   geometry().x()
+ *   cell_nodes   [ncells][3]   topology 2->0 (== geometry dofmap for affine P1 meshes)
+ *   cell_facets  [ncells][3]   topology 2->1, local facet f opposite local vertex f
+ *   facet_nodes  [nfacets][2]  topology 1->0
+ *   facet_cells  CSR           topology 1->2
+ *   node_cells   CSR           topology 0->2
+ *   node_facets  CSR           topology 0->1
+ *   facet_perm   [ncells][3]   get_facet_permutations(): reflection bit of each cell facet
+ * All pointers are host pointers; nothing is retained.
+ */
+int eqlb_mesh_create(int32_t nnodes, int32_t ncells, int32_t nfacets, const double* x,
+                     const int32_t* cell_nodes, const int32_t* cell_facets,
+                     const int32_t* facet_nodes, const int32_t* facet_cells_offsets,
+                     const int32_t* facet_cells, const int32_t* node_cells_offsets,
+                     const int32_t* node_cells, const int32_t* node_facets_offsets,
+                     const int32_t* node_facets, const uint8_t* facet_perm,
+                     eqlb_mesh_t** mesh);
+void eqlb_mesh_destroy(eqlb_mesh_t* mesh);
+
+/*
+ * Semi-explicit equilibrator for RT_k fluxes with projected flux / RHS in DG_{degree_dg}
+ * (degree_dg <= k-1; the reference requires deg(flux_dg) == deg(rhs_dg) <= k-1,
+ * se/reconstruction.hpp:363-373) and nrhs simultaneously equilibrated fluxes.
+ * Replaces the per-call setup of se::reconstruction<T,k> (se/reconstruction.hpp:62-163:
+ * KernelData tabulation, kernel generation, Patch/PatchData allocation) - done once here and
+ * cached on the device.  reconstruct_stress / korn are the flags of
+ * reconstruct_fluxes_semiexplt[_with_kornconst] (wrappers.cpp:97-137); stress equilibration
+ * is not in this build (EQLB_ERR_UNSUPPORTED).
+ */
+int eqlb_se_create(eqlb_mesh_t* mesh, int32_t k, int32_t degree_dg, int32_t nrhs,
+                   int32_t reconstruct_stress, int32_t estimate_korn, eqlb_se_t** handle);
+void eqlb_se_destroy(eqlb_se_t* handle);
+
+/* Integer options: "solver" (EQLB_SOLVER_*), "scatter" (EQLB_SCATTER_*). */
+int eqlb_se_set_option(eqlb_se_t* handle, const char* key, int32_t value);
+
+/*
+ * Boundary information = the tables base::BoundaryData hands to the patch loop
+ * (base/BoundaryData.hpp: facet_type(), boundary_values(); built by
+ * base/BoundaryData.cpp:279-633 from the FluxBC lists):
+ *   facet_type       [nrhs][nfacets] int8, EQLB_FACET_*
+ *   boundary_values  [nrhs][ncells*k(k+2)] global boundary DOFs of the flux, or NULL for
+ *                    homogeneous flux BCs.  Inhomogeneous data is not in this build
+ *                    (per-patch hat*g DOFs, base/BoundaryData.cpp:687-745): a non-NULL array
+ *                    with a non-zero entry returns EQLB_ERR_UNSUPPORTED.
+ *   node_mask        [nnodes] uint8 or NULL: equilibrate only patches of nodes with mask != 0
+ *                    (node ownership of a partitioned run; the reference loops
+ *                    index_map(0)->size_local() owned nodes, se/reconstruction.hpp:90,286).
+ * Builds the oriented patch fans (OrientedPatch::initialize_patch, se/Patch.cpp:406-635, and
+ * the reversal flags of se/solve_patch_semiexplt.hpp:324-389) with a HIP kernel into
+ * lane-contiguous SoA buffers, binned by patch size.  Host pointers.
+ */
+int eqlb_se_set_boundary(eqlb_se_t* handle, const int8_t* facet_type,
+                         const double* boundary_values, const uint8_t* node_mask);
+
+/*
+ * The hot path: se::reconstruction<T,k> node loop (se/reconstruction.hpp:286-313) =
+ * for every patch: explicit step, patch assembly, small dense factorise/solve, back-map and
+ * scatter (se/solve_patch_semiexplt.hpp:212-1163).  Replaces the body of
+ * reconstruct_fluxes_semiexplt (wrappers.cpp:97-115).
+ *   flux_dg    [nrhs][ncells*nd*2]   projected fluxes, DG_{degree_dg}^2 blocked (x,y per node),
+ *                                    = flux_dg[i]->x()->array()  (solve_patch_semiexplt.hpp:456)
+ *   rhs_dg     [nrhs][ncells*nd]     projected right-hand sides   (:462)
+ *   flux_hdiv  [nrhs][ncells*k(k+2)] equilibrated correctors in the discontinuous hierarchic
+ *                                    RT_k space, global DOF = cell*k(k+2)+local
+ *                                    (se/Patch.hpp:480); ACCUMULATED (+=) like the reference
+ *                                    (solve_patch_semiexplt.hpp:1157-1160)
+ *   memspace   EQLB_MEM_HOST: pointers are host memory (copied in and out, synchronous);
+ *              EQLB_MEM_DEVICE: device pointers, work is enqueued on `stream` (hipStream_t,
+ *              NULL = default stream) and the call returns without synchronising.
+ */
+int eqlb_se_equilibrate(eqlb_se_t* handle, const double* flux_dg, const double* rhs_dg,
+                        double* flux_hdiv, int32_t memspace, void* stream);
+
+/* Number of patches equilibrated per call (nodes selected by node_mask). */
+int64_t eqlb_se_num_patches(const eqlb_se_t* handle);
+
+/*
+ * Test/diagnostic export of the device-built patch fans in the layout of
+ * OrientedPatch (_cells, _fcts, _fcts_local, _inodes_local; se/Patch.hpp:371-376), one row of
+ * `stride` (>= max cells per patch + 2) entries per mesh node, unused entries -1:
+ *   ncells [nnodes], cells [nnodes][stride], fcts [nnodes][stride],
+ *   fcts_local [nnodes][2*stride], inodes_local [nnodes][stride], reversed [nnodes][2*stride]
+ *   ([2a], [2a+1] = E_{a-1} / E_a of cell T_a reversed, 0-based cell a).  Host pointers.
+ */
+int eqlb_se_export_patches(eqlb_se_t* handle, int32_t stride, int32_t* ncells, int32_t* cells,
+                           int32_t* fcts, int8_t* fcts_local, int8_t* inodes_local,
+                           int8_t* reversed);
+
+/* Largest number of cells of a patch of the mesh (OrientedPatch::ncells_max). */
+int32_t eqlb_mesh_max_patch_cells(const eqlb_mesh_t* mesh);
+
+/*
+ * Constant reference-cell tensors compiled into the library (tools/gen_tables.py), for tests:
+ * name in {"S","F","H","D","B"}; returns the number of doubles copied (<= capacity), or a
+ * negative error.
+ */
+int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, double* out,
+                             int32_t capacity);
+
+/* Average device time in ms of the patch kernel launches of the last equilibrate call
+ * measured with HIP events on the launch stream (0 if timing is disabled). "timing" option. */
+double eqlb_se_last_kernel_ms(const eqlb_se_t* handle, int32_t which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EQLB_H */
