@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libeqlb_amd.so")
+LIB_PATH = os.environ.get("EQLB_AMD_LIB", os.path.join(_HERE, "libeqlb_amd.so"))
 
 MEM_HOST, MEM_DEVICE = 0, 1
 SOLVER_LDS_CHOLESKY, SOLVER_SHUFFLE = 0, 1

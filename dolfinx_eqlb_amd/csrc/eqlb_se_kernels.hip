@@ -481,60 +481,106 @@ __global__ void __launch_bounds__((Sizes<K, DEG, P>::BLOCK)) k_se_patch(const Se
       const int ntri = dim * (dim + 1) / 2;
       for (int e = sub; e < ntri; e += P)
         Ag[e] = 0.0;
-      for (int e = sub; e < dim; e += P)
-        bg[e] = 0.0;
       int gi[NH];
-      bool fx[NH];
       gi[0] = 0;
-      fx[0] = d_fixed;
 #pragma unroll
       for (int j = 0; j < KB; ++j)
       {
         gi[1 + j] = 1 + sub * KB + j;
-        fx[1 + j] = bc0 && sub == 0;
         gi[1 + KB + j] = 1 + fi_p * KB + j;
-        fx[1 + KB + j] = bcn && sub == n - 1;
       }
 #pragma unroll
       for (int q = 0; q < NADD; ++q)
-      {
         gi[1 + 2 * KB + q] = 1 + nf * KB + sub * NADD + q;
-        fx[1 + 2 * KB + q] = false;
-      }
       wave_sync();
-      // deterministic assembly: the lanes of a group add their element matrices one after another
-      for (int s = 0; s < P; ++s)
+
+      // Conflict-free assembly of the patch tile (se/assembly.hpp:182-272 scatter-add): lane i owns
+      // the rows of facet E_i = own minus-side blocks + plus-side blocks of the previous cell
+      // (fetched by shuffle), the E_i/E_{i+1} coupling of its cell and its interior unknowns; every
+      // tile entry is stored exactly once, fixed (flux-BC) unknowns become identity rows (:209-251).
+      const int prevl = (sub > 0) ? sub - 1 : nn - 1;
+      const bool has_prevcell = pvalid && sub < nf && (sub > 0 || interior_geo);
+      const bool fx_m = (bc0 && sub == 0) || (bcn && sub == n); // facet E_sub fixed
+      const bool fx_p = bcn && sub == n - 1;                     // facet E_{sub+1} fixed
       {
-        if (sub == s && active)
+        double sdd = Te[0][0], sld = Le[0];
+#pragma unroll
+        for (int off = 1; off < P; off <<= 1)
         {
+          sdd += shfl_d(sdd, gbase + (sub ^ off));
+          sld += shfl_d(sld, gbase + (sub ^ off));
+        }
+        if (sub == 0 && pvalid)
+        {
+          Ag[0] = d_fixed ? 1.0 : sdd;
+          bg[0] = d_fixed ? 0.0 : sld;
+        }
+      }
 #pragma unroll
-          for (int h = 0; h < NH; ++h)
+      for (int aa = 0; aa < KB; ++aa)
+      {
+        const double dp_prev = shfl_d(Te[0][1 + KB + aa], gbase + prevl);
+        const double lp_prev = shfl_d(Le[1 + KB + aa], gbase + prevl);
+        const int row = 1 + sub * KB + aa;
+        if (pvalid && sub < nf)
+        {
+          const double bt = Te[0][1 + aa] + (has_prevcell ? dp_prev : 0.0);
+          const double rr = Le[1 + aa] + (has_prevcell ? lp_prev : 0.0);
+          Ag[tri(row, 0)] = (fx_m || d_fixed) ? 0.0 : bt;
+          bg[row] = fx_m ? 0.0 : rr;
+        }
+#pragma unroll
+        for (int bb = 0; bb <= aa; ++bb)
+        {
+          const double pp_prev = shfl_d(Te[1 + KB + aa][1 + KB + bb], gbase + prevl);
+          if (pvalid && sub < nf)
           {
-            if (!fx[h])
-            {
-              bg[gi[h]] += Le[h];
-#pragma unroll
-              for (int g = 0; g < NH; ++g)
-                if (!fx[g] && gi[h] >= gi[g]) // distinct local unknowns have distinct numbers
-                  Ag[tri(gi[h], gi[g])] += Te[h][g];
-            }
+            const double dg = Te[1 + aa][1 + bb] + (has_prevcell ? pp_prev : 0.0);
+            Ag[tri(row, 1 + sub * KB + bb)] = fx_m ? ((aa == bb) ? 1.0 : 0.0) : dg;
           }
         }
-        wave_sync();
+        if (active)
+        {
+          // coupling of E_sub (um) with E_{fi_p} (up) inside the own cell
+#pragma unroll
+          for (int bb = 0; bb < KB; ++bb)
+          {
+            const int col = 1 + fi_p * KB + bb;
+            const double v = (fx_m || fx_p) ? 0.0 : Te[1 + aa][1 + KB + bb];
+            if (row > col)
+              Ag[tri(row, col)] = v;
+            else
+              Ag[tri(col, row)] = v;
+          }
+        }
       }
-      // identity rows of fixed unknowns (se/assembly.hpp:209-251)
-      if (sub == 0 && pvalid)
+      if (active)
       {
-        if (d_fixed)
-          Ag[0] = 1.0;
-        if (bc0)
-          for (int j = 0; j < KB; ++j)
-            Ag[tri(1 + j, 1 + j)] = 1.0;
-        if (bcn)
-          for (int j = 0; j < KB; ++j)
-            Ag[tri(1 + n * KB + j, 1 + n * KB + j)] = 1.0;
+#pragma unroll
+        for (int q = 0; q < NADD; ++q)
+        {
+          const int row = 1 + nf * KB + sub * NADD + q;
+          Ag[tri(row, 0)] = d_fixed ? 0.0 : Te[0][1 + 2 * KB + q];
+          bg[row] = Le[1 + 2 * KB + q];
+#pragma unroll
+          for (int aa = 0; aa < KB; ++aa)
+          {
+            Ag[tri(row, 1 + sub * KB + aa)] = fx_m ? 0.0 : Te[1 + aa][1 + 2 * KB + q];
+            Ag[tri(row, 1 + fi_p * KB + aa)] = fx_p ? 0.0 : Te[1 + KB + aa][1 + 2 * KB + q];
+          }
+#pragma unroll
+          for (int q2 = 0; q2 <= q; ++q2)
+            Ag[tri(row, row - q + q2)] = Te[1 + 2 * KB + q][1 + 2 * KB + q2];
+        }
       }
       wave_sync();
+#ifdef EQLB_DEBUG
+      if (patch == 0 && r == 0 && sub == 0)
+        for (int i = 0; i < dim; ++i)
+          for (int j = 0; j <= i; ++j)
+            printf("[dbg] A[%d][%d] = %g   b %g\n", i, j, Ag[tri(i, j)], bg[i]);
+      wave_sync();
+#endif
       // Cholesky, column by column
       for (int j = 0; j < dim; ++j)
       {
