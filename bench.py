@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: equilibrated patches/s (fp64) of the semi-explicit flux equilibration
+(FluxEqlbSE, RT_2) on a 1M-triangle Poisson case per GPU (BASELINE.json configs[1]).
+
+A step = one eqlb_se_equilibrate call = the reference's timed region, one
+`equilibrate_fluxes()` (python/test/performance/perftest.py:145-147), over all patches of the
+mesh, with the inputs (projected flux, projected RHS) and the output resident in HBM and the
+patch SoA / reference tensors cached in the handle ("warm").
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--n 500] [--k 2]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the unit-square strips of the
+ranks form one [0,N]x[0,1] domain; patches are partitioned by node ownership and the partial
+sums of the ghost-cell RT DOFs are exchanged with the strip neighbours (RCCL send/recv) inside
+the timed step - weak scaling, 1M triangles per GPU.
+
+Rank 0 prints ONE JSON line (contract in the task description) with `roofline` (dominant
+kernel, HIP-event time measured live over the timed region) and `cpu_baseline` (the CPU
+restatement of the reference algorithm, oracle/, timed on this box's host cores).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=500, help="squares per side and GPU (500 -> 1M triangles)")
+    ap.add_argument("--k", type=int, default=2, help="RT degree")
+    ap.add_argument("--solver", type=int, default=None)
+    ap.add_argument("--scatter", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shuffle", type=int, default=None, help="seed for random local vertex order")
+    return ap.parse_args()
+
+
+def compulsory_bytes_per_cell(k, nrhs):
+    """8 R [k(k+1) + k(k+1)/2 + k(k+2)] + 24 bytes per cell."""
+    return 8 * nrhs * (k * (k + 1) + k * (k + 1) // 2 + k * (k + 2)) + 24
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from dolfinx_eqlb_amd import cpp
+    from dolfinx_eqlb_amd import distributed as dd
+    from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
+    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    k, n = args.k, args.n
+    nrt, nd = k * (k + 2), k * (k + 1) // 2
+
+    # ---- problem setup (not timed): mesh strip of this rank, compatible synthetic data ----
+    part = dd.StripPartition(n, rank, world, shuffle_seed=args.shuffle)
+    mesh = part.mesh
+    ft = part.facet_types()
+    G, f = make_compatible_data(mesh, k, ft, seed=20241003 + rank)
+    dmesh = cpp.DeviceMesh(mesh)
+    eq = cpp.SemiExplicitEquilibrator(dmesh, k, 1)
+    if args.solver is not None:
+        eq.set_option("solver", args.solver)
+    if args.scatter is not None:
+        eq.set_option("scatter", args.scatter)
+    eq.set_boundary(ft, node_mask=part.node_mask)
+    npatch_local = eq.num_patches
+
+    d_G = torch.from_numpy(G).to(dev)
+    d_f = torch.from_numpy(f).to(dev)
+    d_x = torch.zeros(mesh.ncells * nrt, dtype=torch.float64, device=dev)
+    halo = dd.HaloExchange(part, nrt, dev) if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eq.equilibrate_device(d_G.data_ptr(), d_f.data_ptr(), d_x.data_ptr(), stream)
+        if halo is not None:
+            halo.reduce(d_x)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # correctness of this very configuration (single sweep into a zeroed vector)
+    step()
+    torch.cuda.synchronize()
+    x_host = d_x.cpu().numpy().copy()
+    res = nrm = None
+    if world == 1:
+        res, nrm = chk.divergence_residual(mesh, k, x_host, G, f)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    eq.set_option("timing", 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([npatch_local], dtype=torch.float64, device=dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        npatch_total = int(cnt.item())
+    else:
+        npatch_total = npatch_local
+
+    # ---- per-kernel device times (HIP events recorded on the launch stream in the timed loop)
+    bins_ms = [eq.last_kernel_ms(b) for b in range(5)]
+    reduce_ms = eq.last_kernel_ms(5)
+    eq.set_option("timing", 0)
+    ncells_bin = part.patch_cells_per_bin()  # patch-cells handled by each bin's launch
+    dom = int(np.argmax(bins_ms))
+    total_pc = float(sum(ncells_bin))
+    bytes_sweep = compulsory_bytes_per_cell(k, 1) * part.ncells_owned
+    alg_bytes = bytes_sweep * ncells_bin[dom] / total_pc  # share of the sweep done by that launch
+    achieved = alg_bytes / (bins_ms[dom] * 1e-3) / 1e9 if bins_ms[dom] > 0 else 0.0
+    peak = 8000.0
+
+    out = {
+        "metric": "equilibrated patches/s (fp64) on 1M-tri Poisson k=2; L2 flux-divergence residual",
+        "value": npatch_total * args.steps / elapsed,
+        "unit": "patches/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"Poisson {4 * n * n} triangles per GPU (crossed unit square {n}x{n}), "
+                        f"P{k} primal, FluxEqlbSE RT{k}, homogeneous Dirichlet, fp64",
+            "patches_per_gpu": npatch_local, "cells_per_gpu": int(part.ncells_owned),
+            "nrhs": 1, "partition": "node-ownership strips" if world > 1 else "none",
+            "solver": eq_solver_name(args.solver), "scatter": eq_scatter_name(args.scatter),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": f"k_se_patch<K={k},P={4 << dom}>",
+            "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel_ms": bins_ms[dom],
+            "all_kernels_ms": {f"patch_P{4 << b}": bins_ms[b] for b in range(5) if bins_ms[b] > 0}
+            | ({"reduce_slots": reduce_ms} if reduce_ms > 0 else {}),
+        },
+    }
+    if res is not None:
+        out["div_residual_L2"] = res
+        out["rhs_norm_L2"] = nrm
+        out["div_residual_rel"] = res / nrm
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(mesh, k, ft, G, f, npatch_local)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def eq_solver_name(v):
+    return {None: "lds_cholesky", 0: "lds_cholesky", 1: "shuffle"}[v]
+
+
+def eq_scatter_name(v):
+    return {None: "slots", 0: "slots", 1: "atomic"}[v]
+
+
+def cpu_baseline(mesh, k, ft, G, f, npatch):
+    """Single-thread CPU restatement of the reference algorithm (oracle/eqlb_oracle.c) on the
+    same mesh and data.  The whole sweep takes only a few seconds on one core, so the sample is
+    the complete workload (all patches), best of 3."""
+    from oracle import oracle
+    x = np.zeros((1, mesh.ncells * k * (k + 2)))
+    best = None
+    for rep in range(3):
+        t0 = time.perf_counter()
+        oracle.se_reconstruct(mesh, k, ft, G[None], f[None], flux_hdiv=x)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": mesh.nnodes / best, "unit": "patches/s", "cores": 1, "kind": "port",
+            "sample": f"all {npatch} patches of the workload (one full sweep), best of 3, "
+                      f"{best:.2f} s per sweep",
+            "note": "CPU restatement of the reference algorithm (not the dolfinx_eqlb binary)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -209,9 +209,12 @@ void eqlb_se_destroy(eqlb_se_t* h)
   dfree(h->d_flux_dg);
   dfree(h->d_rhs_dg);
   dfree(h->d_flux_hdiv);
-  for (auto& e : h->ev)
-    if (e)
-      (void)hipEventDestroy(e);
+  if (h->ev)
+  {
+    for (int i = 0; i < eqlb_se::EV_RING * eqlb_se::EV_PER_SET; ++i)
+      (void)hipEventDestroy(h->ev[i]);
+    delete[] h->ev;
+  }
   delete h;
 }
 
@@ -232,7 +235,10 @@ int eqlb_se_set_option(eqlb_se_t* h, const char* key, int32_t value)
     h->scatter = value;
   }
   else if (!strcmp(key, "timing"))
+  {
     h->timing = value;
+    h->ev_calls = 0;
+  }
   else
     return fail(EQLB_ERR_INVALID_ARGUMENT, "unknown option '%s'", key);
   return EQLB_OK;
@@ -255,6 +261,8 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
   // OrientedPatch::set_max_patch_size (se/Patch.cpp:337-404): every local node is checked
   for (int32_t i = 0; i < m.nnodes; ++i)
   {
+    if (node_mask && !node_mask[i])
+      continue; // the reference loops the owned nodes only (size_local)
     if (m.h_node_ncells[i] == 1)
       return fail(EQLB_ERR_PATCH_TOO_SMALL, "Patch around node %d has only 1 cells.", i);
     if (m.h_node_ncells[i] < 1)
@@ -460,9 +468,17 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
     // slots of (cell, vertex) pairs whose node is not equilibrated (node_mask) stay zero
     HIP_TRY(hipMemset(h->slots, 0, n_x * 3 * sizeof(double)));
   }
-  if (h->timing && !h->ev[0])
-    for (auto& e : h->ev)
-      HIP_TRY(hipEventCreate(&e));
+  hipEvent_t* evs = nullptr;
+  if (h->timing)
+  {
+    if (!h->ev)
+    {
+      h->ev = new hipEvent_t[eqlb_se::EV_RING * eqlb_se::EV_PER_SET];
+      for (int i = 0; i < eqlb_se::EV_RING * eqlb_se::EV_PER_SET; ++i)
+        HIP_TRY(hipEventCreate(&h->ev[i]));
+    }
+    evs = h->ev + (h->ev_calls % eqlb_se::EV_RING) * eqlb_se::EV_PER_SET;
+  }
 
   eqlb::SeArgs a{};
   a.cellJ = m.cellJ;
@@ -479,9 +495,6 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
   a.ncells = m.ncells;
   a.nrhs = h->nrhs;
 
-  if (h->timing)
-    HIP_TRY(hipEventRecord(h->ev[0], stream));
-  h->n_patch_launches = 0;
   for (int b = 0; b < eqlb::MAX_BINS; ++b)
   {
     if (h->bins[b].npatch == 0)
@@ -489,20 +502,24 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
     a.npatch = h->bins[b].npatch;
     a.slot_offset = h->bins[b].slot_offset;
     a.patch_offset = h->bins[b].patch_offset;
+    if (evs)
+      HIP_TRY(hipEventRecord(evs[2 * b], stream));
     const int st = eqlb::launch_se_patch(h->k, h->deg, h->bins[b].P, h->solver, h->scatter, a, stream);
     if (st)
       return fail(st, "patch kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
-    ++h->n_patch_launches;
+    if (evs)
+      HIP_TRY(hipEventRecord(evs[2 * b + 1], stream));
   }
-  if (h->timing)
-    HIP_TRY(hipEventRecord(h->ev[1], stream));
   if (h->scatter == EQLB_SCATTER_SLOTS)
-    eqlb::launch_reduce_slots(h->nrt, m.ncells, h->nrhs, h->slots, d_x, stream);
-  if (h->timing)
   {
-    HIP_TRY(hipEventRecord(h->ev[2], stream));
-    h->ev_valid = true;
+    if (evs)
+      HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS], stream));
+    eqlb::launch_reduce_slots(h->nrt, m.ncells, h->nrhs, h->slots, d_x, stream);
+    if (evs)
+      HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS + 1], stream));
   }
+  if (evs)
+    ++h->ev_calls;
   HIP_TRY(hipGetLastError());
 
   if (memspace == EQLB_MEM_HOST)
@@ -522,19 +539,27 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
 
 double eqlb_se_last_kernel_ms(const eqlb_se_t* h, int32_t which)
 {
-  if (!h || !h->ev_valid)
+  // which = b (0..4): patch kernel of bin b (P = 4 << b); 5: slot reduction.
+  // Average device time per launch over the calls recorded since timing was enabled
+  // (at most the last EV_RING calls).  Synchronises with the recorded events.
+  if (!h || !h->ev || h->ev_calls == 0 || which < 0 || which > eqlb::MAX_BINS)
     return 0.0;
-  float ms = 0.f;
-  if (hipEventSynchronize(h->ev[2]) != hipSuccess)
+  if (which < eqlb::MAX_BINS && h->bins[which].npatch == 0)
     return 0.0;
-  hipError_t e = hipSuccess;
-  if (which == 0) // patch kernels (all bins)
-    e = hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
-  else if (which == 1) // slot reduction
-    e = hipEventElapsedTime(&ms, h->ev[1], h->ev[2]);
-  else
-    e = hipEventElapsedTime(&ms, h->ev[0], h->ev[2]);
-  return (e == hipSuccess) ? (double)ms : 0.0;
+  if (which == eqlb::MAX_BINS && h->scatter != EQLB_SCATTER_SLOTS)
+    return 0.0;
+  const int64_t nset = std::min<int64_t>(h->ev_calls, eqlb_se::EV_RING);
+  double sum = 0.0;
+  for (int64_t s = 0; s < nset; ++s)
+  {
+    hipEvent_t* evs = h->ev + s * eqlb_se::EV_PER_SET;
+    float ms = 0.f;
+    if (hipEventSynchronize(evs[2 * which + 1]) != hipSuccess
+        || hipEventElapsedTime(&ms, evs[2 * which], evs[2 * which + 1]) != hipSuccess)
+      return 0.0;
+    sum += ms;
+  }
+  return sum / (double)nset;
 }
 
 int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, double* out,

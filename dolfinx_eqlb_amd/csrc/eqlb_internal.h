@@ -126,8 +126,8 @@ struct eqlb_se
   int32_t* status = nullptr;
   // staging for host-memory calls
   double *d_flux_dg = nullptr, *d_rhs_dg = nullptr, *d_flux_hdiv = nullptr;
-  // timing
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool ev_valid = false;
-  int n_patch_launches = 0;
+  // timing ("timing" option): ring of event sets, one set per equilibrate call
+  static constexpr int EV_RING = 64, EV_PER_SET = 2 * eqlb::MAX_BINS + 2;
+  hipEvent_t* ev = nullptr; // [EV_RING][EV_PER_SET]: bin b start/end at 2b, 2b+1; reduce start/end
+  int64_t ev_calls = 0;     // calls recorded since timing was (re)enabled
 };

@@ -105,6 +105,62 @@ def _shuffle_local_order(cell_nodes, seed):
     return np.take_along_axis(cell_nodes, perms[pick], axis=1)
 
 
+def create_rectangle(nx: int, ny: int, x0: float = 0.0, x1: float = 1.0, y0: float = 0.0,
+                     y1: float = 1.0, diagonal: str = "crossed", shuffle_seed=None,
+                     perturb: float = 0.0, perturb_seed: int = 7, keep_cell=None,
+                     return_grid_ids: bool = False):
+    """Structured triangulation of [x0,x1] x [y0,y1] with nx x ny squares.
+
+    crossed: 4 triangles per square in the order (v00,v10,c), (v10,v11,c), (v11,v01,c),
+    (v01,v00,c) (bottom, right, top, left), cell id (j*nx + i)*4 + t; right: 2 per square.
+    keep_cell: optional callable(i, j, t) -> bool mask to drop cells (used for ghost layers).
+    """
+    ii, jj = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), indexing="xy")
+    corners = np.stack([x0 + (x1 - x0) * ii.ravel() / nx, y0 + (y1 - y0) * jj.ravel() / ny], axis=1)
+    ci, cj = np.meshgrid(np.arange(nx), np.arange(ny), indexing="xy")
+    ci, cj = ci.ravel(), cj.ravel()
+    v00 = cj * (nx + 1) + ci
+    v10 = v00 + 1
+    v01 = v00 + (nx + 1)
+    v11 = v01 + 1
+    if diagonal == "crossed":
+        centres = np.stack([x0 + (x1 - x0) * (ci + 0.5) / nx, y0 + (y1 - y0) * (cj + 0.5) / ny], axis=1)
+        c = (nx + 1) * (ny + 1) + cj * nx + ci
+        x2d = np.concatenate([corners, centres])
+        cells = np.stack([np.stack([v00, v10, c], 1), np.stack([v10, v11, c], 1),
+                          np.stack([v11, v01, c], 1), np.stack([v01, v00, c], 1)], axis=1)
+        nt = 4
+    elif diagonal == "right":
+        x2d = corners
+        cells = np.stack([np.stack([v00, v10, v11], 1), np.stack([v00, v11, v01], 1)], axis=1)
+        nt = 2
+    else:
+        raise ValueError("diagonal must be 'crossed' or 'right'")
+    cells = cells.reshape(-1, 3)
+    gi = np.repeat(ci, nt)
+    gj = np.repeat(cj, nt)
+    gt = np.tile(np.arange(nt), ci.size)
+    if keep_cell is not None:
+        keep = keep_cell(gi, gj, gt)
+        cells, gi, gj, gt = cells[keep], gi[keep], gj[keep], gt[keep]
+
+    if perturb > 0.0:
+        rng = np.random.default_rng(perturb_seed)
+        eps = 1e-12
+        interior = (x2d[:, 0] > x0 + eps) & (x2d[:, 0] < x1 - eps) \
+            & (x2d[:, 1] > y0 + eps) & (x2d[:, 1] < y1 - eps)
+        x2d = x2d.copy()
+        h = min((x1 - x0) / nx, (y1 - y0) / ny)
+        x2d[interior] += perturb * h * (rng.random((interior.sum(), 2)) - 0.5)
+
+    if shuffle_seed is not None:
+        cells = _shuffle_local_order(cells, shuffle_seed)
+    mesh = create_mesh(x2d, cells.astype(np.int32))
+    if return_grid_ids:
+        return mesh, (gi, gj, gt)
+    return mesh
+
+
 def create_unit_square(n: int, diagonal: str = "crossed", shuffle_seed=None,
                        perturb: float = 0.0, perturb_seed: int = 7) -> Mesh:
     """Unit square, n x n squares, `crossed` (4 triangles per square, as
@@ -113,35 +169,5 @@ def create_unit_square(n: int, diagonal: str = "crossed", shuffle_seed=None,
     shuffle_seed: None -> canonical counter-clockwise cells; int -> random local vertex order.
     perturb:      relative random displacement of interior nodes (irregular geometry).
     """
-    ii, jj = np.meshgrid(np.arange(n + 1), np.arange(n + 1), indexing="xy")
-    corners = np.stack([ii.ravel() / n, jj.ravel() / n], axis=1)
-    ci, cj = np.meshgrid(np.arange(n), np.arange(n), indexing="xy")
-    ci, cj = ci.ravel(), cj.ravel()
-    v00 = cj * (n + 1) + ci
-    v10 = v00 + 1
-    v01 = v00 + (n + 1)
-    v11 = v01 + 1
-    if diagonal == "crossed":
-        centres = np.stack([(ci + 0.5) / n, (cj + 0.5) / n], axis=1)
-        c = (n + 1) ** 2 + cj * n + ci
-        x2d = np.concatenate([corners, centres])
-        cells = np.stack([np.stack([v00, v10, c], 1), np.stack([v10, v11, c], 1),
-                          np.stack([v11, v01, c], 1), np.stack([v01, v00, c], 1)], axis=1)
-        cells = cells.reshape(-1, 3)
-    elif diagonal == "right":
-        x2d = corners
-        cells = np.stack([np.stack([v00, v10, v11], 1), np.stack([v00, v11, v01], 1)], axis=1)
-        cells = cells.reshape(-1, 3)
-    else:
-        raise ValueError("diagonal must be 'crossed' or 'right'")
-
-    if perturb > 0.0:
-        rng = np.random.default_rng(perturb_seed)
-        interior = (x2d[:, 0] > 1e-12) & (x2d[:, 0] < 1 - 1e-12) \
-            & (x2d[:, 1] > 1e-12) & (x2d[:, 1] < 1 - 1e-12)
-        x2d = x2d.copy()
-        x2d[interior] += perturb / n * (rng.random((interior.sum(), 2)) - 0.5)
-
-    if shuffle_seed is not None:
-        cells = _shuffle_local_order(cells, shuffle_seed)
-    return create_mesh(x2d, cells.astype(np.int32))
+    return create_rectangle(n, n, diagonal=diagonal, shuffle_seed=shuffle_seed, perturb=perturb,
+                            perturb_seed=perturb_seed)

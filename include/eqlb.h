@@ -161,8 +161,11 @@ int32_t eqlb_mesh_max_patch_cells(const eqlb_mesh_t* mesh);
 int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, double* out,
                              int32_t capacity);
 
-/* Average device time in ms of the patch kernel launches of the last equilibrate call
- * measured with HIP events on the launch stream (0 if timing is disabled). "timing" option. */
+/* With option "timing" = 1 every equilibrate call records HIP events on the launch stream around
+ * each kernel (ring of the last 64 calls).  Returns the average device time in ms per launch of
+ * kernel `which` over the recorded calls: which = b in 0..4: patch kernel of the bin with
+ * P = 4 << b lanes per patch; which = 5: slot-reduction kernel.  Synchronises with the events;
+ * 0 if nothing was recorded.  Setting the option again resets the ring. */
 double eqlb_se_last_kernel_ms(const eqlb_se_t* handle, int32_t which);
 
 #ifdef __cplusplus

@@ -1245,8 +1245,9 @@ int oracle_se_reconstruct(const oracle_mesh_t* mesh, const oracle_tables_t* tab,
                           const double* flux_dg, const double* rhs_dg, double* flux_hdiv,
                           int32_t node_begin, int32_t node_end)
 {
-  /* OrientedPatch::set_max_patch_size, se/Patch.cpp:337-404 (ncells_min = 1) */
-  for (int i = 0; i < mesh->nnodes; ++i)
+  /* OrientedPatch::set_max_patch_size, se/Patch.cpp:337-404 (ncells_min = 1): checks the
+   * nodes the loop visits (size_local owned nodes in the reference) */
+  for (int i = node_begin; i < node_end; ++i)
     if (mesh->node_cells_off[i + 1] - mesh->node_cells_off[i] == 1)
       return -1;
   patch_t p;
