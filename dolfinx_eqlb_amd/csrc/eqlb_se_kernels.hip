@@ -635,10 +635,362 @@ __global__ void __launch_bounds__((Sizes<K, DEG, P>::BLOCK)) k_se_patch(const Se
     }
     else
     {
-      // SOLVER 1 is provided by a separate specialisation (see below); unreachable here
+      // ---- SOLVER 1: everything in registers, lane-to-lane hand-off by shuffles ----
+      // Unknown layout: border z = [d ; x_0] (x_i = the KB higher moments of facet E_i), chain
+      // x_1 .. x_{nf-1} block tridiagonal.  Lane i holds the block row of facet E_i.
+      static_assert(NADD <= 1, "interior-DOF condensation is written for at most one DOF per cell");
+      constexpr int W = K;         // border width
+      constexpr int NC = 1 + 2 * KB; // core local unknowns [d | um | up]
+      const bool fx_m = (bc0 && sub == 0) || (bcn && sub == n); // facet E_sub fixed (flux BC)
+      const bool fx_p = bcn && sub == n - 1;                     // facet E_{sub+1} fixed
+      const int prevl = (sub > 0) ? sub - 1 : nn - 1;
+      const bool has_prevcell = pvalid && sub < nf && (sub > 0 || interior_geo);
+
+      // (a) masked copy of the element system (identity rows of se/assembly.hpp:209-251)
+      double T[NH][NH], Lv[NH];
 #pragma unroll
       for (int h = 0; h < NH; ++h)
-        ul[h] = 0.0;
+      {
+        const bool fh = (h == 0) ? d_fixed : ((h <= KB) ? fx_m : ((h <= 2 * KB) ? fx_p : false));
+        Lv[h] = fh ? 0.0 : Le[h];
+#pragma unroll
+        for (int g = 0; g < NH; ++g)
+        {
+          const bool fg = (g == 0) ? d_fixed : ((g <= KB) ? fx_m : ((g <= 2 * KB) ? fx_p : false));
+          T[h][g] = (fh || fg) ? 0.0 : Te[h][g];
+        }
+      }
+      // (b) static condensation of the cell-interior unknown (k >= 3)
+      double ca[NC], la = 0.0;
+#pragma unroll
+      for (int h = 0; h < NC; ++h)
+        ca[h] = 0.0;
+      if constexpr (NADD == 1)
+      {
+        const double piv = active ? T[NC][NC] : 1.0;
+        const double ip = 1.0 / piv;
+        la = Lv[NC] * ip;
+#pragma unroll
+        for (int h = 0; h < NC; ++h)
+          ca[h] = T[h][NC] * ip;
+#pragma unroll
+        for (int h = 0; h < NC; ++h)
+        {
+          Lv[h] -= T[h][NC] * la;
+#pragma unroll
+          for (int g = 0; g < NC; ++g)
+            T[h][g] -= ca[h] * T[NC][g];
+        }
+      }
+      // (c) block row of facet E_sub: own minus-side blocks + plus-side blocks of the previous cell
+      double Dg[KB][KB], bt[KB], rr[KB], Off[KB][KB];
+      double alpha = T[0][0], rd = Lv[0];
+#pragma unroll
+      for (int off = 1; off < P; off <<= 1)
+      {
+        alpha += shfl_d(alpha, gbase + (sub ^ off));
+        rd += shfl_d(rd, gbase + (sub ^ off));
+      }
+      if (d_fixed || !pvalid)
+      {
+        alpha = 1.0;
+        rd = 0.0;
+      }
+#pragma unroll
+      for (int aa = 0; aa < KB; ++aa)
+      {
+        const double dp_prev = shfl_d(T[0][1 + KB + aa], gbase + prevl);
+        const double lp_prev = shfl_d(Lv[1 + KB + aa], gbase + prevl);
+        bt[aa] = T[0][1 + aa] + (has_prevcell ? dp_prev : 0.0);
+        rr[aa] = Lv[1 + aa] + (has_prevcell ? lp_prev : 0.0);
+#pragma unroll
+        for (int bb = 0; bb < KB; ++bb)
+        {
+          const double pp_prev = shfl_d(T[1 + KB + aa][1 + KB + bb], gbase + prevl);
+          Dg[aa][bb] = T[1 + aa][1 + bb] + (has_prevcell ? pp_prev : 0.0);
+          Off[aa][bb] = T[1 + aa][1 + KB + bb];
+        }
+      }
+      const bool row_valid = pvalid && sub < nf && !fx_m;
+      if (!row_valid)
+      {
+#pragma unroll
+        for (int aa = 0; aa < KB; ++aa)
+        {
+          bt[aa] = rr[aa] = 0.0;
+#pragma unroll
+          for (int bb = 0; bb < KB; ++bb)
+          {
+            Dg[aa][bb] = (aa == bb) ? 1.0 : 0.0;
+            Off[aa][bb] = 0.0;
+          }
+        }
+      }
+      // (d) border data (lane 0) and the chain rows
+      double Z[W][W], rz[W], Off0[KB][KB];
+      Z[0][0] = alpha;
+      rz[0] = rd;
+#pragma unroll
+      for (int aa = 0; aa < KB; ++aa)
+      {
+        const double b0 = shfl_d(bt[aa], gbase);
+        Z[0][1 + aa] = Z[1 + aa][0] = b0;
+        rz[1 + aa] = shfl_d(rr[aa], gbase);
+#pragma unroll
+        for (int bb = 0; bb < KB; ++bb)
+        {
+          Z[1 + aa][1 + bb] = shfl_d(Dg[aa][bb], gbase);
+          Off0[aa][bb] = shfl_d(Off[aa][bb], gbase);
+        }
+      }
+      const bool in_chain = pvalid && sub >= 1 && sub < nf;
+      const bool wraps = interior_geo && sub == n - 1; // coupling of E_{n-1} to E_n == E_0
+      double Dp[KB][KB], Rp[KB][1 + W], OffC[KB][KB];
+#pragma unroll
+      for (int aa = 0; aa < KB; ++aa)
+      {
+        Rp[aa][0] = in_chain ? rr[aa] : 0.0;
+        Rp[aa][1] = in_chain ? bt[aa] : 0.0;
+#pragma unroll
+        for (int bb = 0; bb < KB; ++bb)
+        {
+          Dp[aa][bb] = in_chain ? Dg[aa][bb] : ((aa == bb) ? 1.0 : 0.0);
+          OffC[aa][bb] = (in_chain && !wraps) ? Off[aa][bb] : 0.0;
+          double c0 = 0.0;
+          if (in_chain && sub == 1)
+            c0 += Off0[bb][aa];
+          if (in_chain && wraps)
+            c0 += Off[aa][bb];
+          Rp[aa][2 + bb] = c0;
+        }
+      }
+      // small SPD inverse (KB = 1, 2), X = Einv Rp, Y = Einv OffC
+      double Ei[KB][KB], X[KB][1 + W], Y[KB][KB];
+      auto finish_row = [&]() {
+        if constexpr (KB == 1)
+          Ei[0][0] = 1.0 / Dp[0][0];
+        else
+        {
+          const double det = Dp[0][0] * Dp[1][1] - Dp[0][1] * Dp[1][0];
+          const double id = 1.0 / det;
+          Ei[0][0] = Dp[1][1] * id;
+          Ei[1][1] = Dp[0][0] * id;
+          Ei[0][1] = -Dp[0][1] * id;
+          Ei[1][0] = -Dp[1][0] * id;
+        }
+#pragma unroll
+        for (int aa = 0; aa < KB; ++aa)
+        {
+#pragma unroll
+          for (int c = 0; c < 1 + W; ++c)
+          {
+            double v = 0.0;
+#pragma unroll
+            for (int e = 0; e < KB; ++e)
+              v += Ei[aa][e] * Rp[e][c];
+            X[aa][c] = v;
+          }
+#pragma unroll
+          for (int bb = 0; bb < KB; ++bb)
+          {
+            double v = 0.0;
+#pragma unroll
+            for (int e = 0; e < KB; ++e)
+              v += Ei[aa][e] * OffC[e][bb];
+            Y[aa][bb] = v;
+          }
+        }
+      };
+      // (e) forward elimination down the chain: lane s receives OffC^T Einv [OffC | Rp] of lane s-1
+#pragma unroll 1
+      for (int s = 2; s < P; ++s)
+      {
+        finish_row();
+        double P1[KB][KB], P2[KB][1 + W];
+#pragma unroll
+        for (int aa = 0; aa < KB; ++aa)
+        {
+#pragma unroll
+          for (int bb = 0; bb < KB; ++bb)
+          {
+            double v = 0.0;
+#pragma unroll
+            for (int e = 0; e < KB; ++e)
+              v += OffC[e][aa] * Y[e][bb];
+            P1[aa][bb] = v;
+          }
+#pragma unroll
+          for (int c = 0; c < 1 + W; ++c)
+          {
+            double v = 0.0;
+#pragma unroll
+            for (int e = 0; e < KB; ++e)
+              v += OffC[e][aa] * X[e][c];
+            P2[aa][c] = v;
+          }
+        }
+        const int src = gbase + ((sub > 0) ? sub - 1 : 0);
+        const bool take = in_chain && sub == s;
+#pragma unroll
+        for (int aa = 0; aa < KB; ++aa)
+        {
+#pragma unroll
+          for (int bb = 0; bb < KB; ++bb)
+          {
+            const double v = shfl_d(P1[aa][bb], src);
+            if (take)
+              Dp[aa][bb] -= v;
+          }
+#pragma unroll
+          for (int c = 0; c < 1 + W; ++c)
+          {
+            const double v = shfl_d(P2[aa][c], src);
+            if (take)
+              Rp[aa][c] -= v;
+          }
+        }
+      }
+      finish_row();
+      // (f) Schur complement of the chain on the border, W x W solve
+      double Sred[W][W], tred[W];
+#pragma unroll
+      for (int c = 0; c < W; ++c)
+      {
+        double v = 0.0;
+#pragma unroll
+        for (int e = 0; e < KB; ++e)
+          v += Rp[e][1 + c] * X[e][0];
+        tred[c] = v;
+#pragma unroll
+        for (int c2 = 0; c2 <= c; ++c2)
+        {
+          double u2 = 0.0;
+#pragma unroll
+          for (int e = 0; e < KB; ++e)
+            u2 += Rp[e][1 + c] * X[e][1 + c2];
+          Sred[c][c2] = u2;
+        }
+      }
+#pragma unroll
+      for (int off = 1; off < P; off <<= 1)
+      {
+#pragma unroll
+        for (int c = 0; c < W; ++c)
+        {
+          tred[c] += shfl_d(tred[c], gbase + (sub ^ off));
+#pragma unroll
+          for (int c2 = 0; c2 <= c; ++c2)
+            Sred[c][c2] += shfl_d(Sred[c][c2], gbase + (sub ^ off));
+        }
+      }
+      double zz[W];
+      {
+        // Cholesky of Z - S (lower), then two triangular solves
+        double Lz[W][W];
+#pragma unroll
+        for (int c = 0; c < W; ++c)
+        {
+          rz[c] -= tred[c];
+#pragma unroll
+          for (int c2 = 0; c2 <= c; ++c2)
+            Lz[c][c2] = Z[c][c2] - Sred[c][c2];
+        }
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+        {
+          double dj = Lz[j][j];
+#pragma unroll
+          for (int q = 0; q < j; ++q)
+            dj -= Lz[j][q] * Lz[j][q];
+          if (!(dj > 0.0))
+          {
+            status_local = pvalid ? 1 : status_local;
+            dj = 1.0;
+          }
+          const double lj = sqrt(dj), ilj = 1.0 / lj;
+          Lz[j][j] = lj;
+#pragma unroll
+          for (int i = j + 1; i < W; ++i)
+          {
+            double v = Lz[i][j];
+#pragma unroll
+            for (int q = 0; q < j; ++q)
+              v -= Lz[i][q] * Lz[j][q];
+            Lz[i][j] = v * ilj;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+        {
+          double v = rz[i];
+#pragma unroll
+          for (int q = 0; q < i; ++q)
+            v -= Lz[i][q] * zz[q];
+          zz[i] = v / Lz[i][i];
+        }
+#pragma unroll
+        for (int i = W - 1; i >= 0; --i)
+        {
+          double v = zz[i];
+#pragma unroll
+          for (int q = i + 1; q < W; ++q)
+            v -= Lz[q][i] * zz[q];
+          zz[i] = v / Lz[i][i];
+        }
+      }
+      // (g) back substitution up the chain
+      double xs[KB];
+#pragma unroll
+      for (int aa = 0; aa < KB; ++aa)
+      {
+        double v = X[aa][0];
+#pragma unroll
+        for (int c = 0; c < W; ++c)
+          v -= X[aa][1 + c] * zz[c];
+        xs[aa] = in_chain ? v : 0.0;
+      }
+#pragma unroll 1
+      for (int s = P - 2; s >= 1; --s)
+      {
+        double xn[KB];
+#pragma unroll
+        for (int aa = 0; aa < KB; ++aa)
+          xn[aa] = shfl_d(xs[aa], gbase + ((sub + 1 < P) ? sub + 1 : sub));
+        if (in_chain && sub == s)
+        {
+#pragma unroll
+          for (int aa = 0; aa < KB; ++aa)
+#pragma unroll
+            for (int bb = 0; bb < KB; ++bb)
+              xs[aa] -= Y[aa][bb] * xn[bb];
+        }
+      }
+      // (h) local unknowns of the cell
+#pragma unroll
+      for (int aa = 0; aa < KB; ++aa)
+        if (sub == 0)
+          xs[aa] = zz[1 + aa];
+      ul[0] = zz[0];
+#pragma unroll
+      for (int aa = 0; aa < KB; ++aa)
+      {
+        ul[1 + aa] = xs[aa];
+        ul[1 + KB + aa] = shfl_d(xs[aa], gbase + ((fi_p < P) ? fi_p : 0));
+      }
+      if constexpr (NADD == 1)
+      {
+        double v = la;
+#pragma unroll
+        for (int h = 0; h < NC; ++h)
+          v -= ca[h] * ul[h];
+        ul[NC] = v;
+      }
+      if (!active)
+      {
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+          ul[h] = 0.0;
+      }
     }
 
     // ---- back-map to RT coefficients and scatter ----
@@ -764,7 +1116,12 @@ static int launch_p(int P, const SeArgs& a, hipStream_t stream)
 template <int K, int DEG>
 static int launch_kd(int P, int solver, int scatter, const SeArgs& a, hipStream_t stream)
 {
-  (void)solver;
+  if (solver == EQLB_SOLVER_SHUFFLE)
+  {
+    if (scatter == EQLB_SCATTER_SLOTS)
+      return launch_p<K, DEG, 1, 0>(P, a, stream);
+    return launch_p<K, DEG, 1, 1>(P, a, stream);
+  }
   if (scatter == EQLB_SCATTER_SLOTS)
     return launch_p<K, DEG, 0, 0>(P, a, stream);
   return launch_p<K, DEG, 0, 1>(P, a, stream);

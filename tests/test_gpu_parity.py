@@ -48,9 +48,10 @@ def test_patch_builder_bit_exact(cpp, oracle_mod):
 @pytest.mark.parametrize("k", [1, 2, 3])
 @pytest.mark.parametrize("bc", ["dirichlet", "neumann_lt", "neumann_bottom"])
 @pytest.mark.parametrize("scatter", [0, 1])
-def test_matches_oracle(cpp, oracle_mod, k, bc, scatter):
+@pytest.mark.parametrize("solver", [0, 1])
+def test_matches_oracle(cpp, oracle_mod, k, bc, scatter, solver):
     mesh, ft, G, f = make_case(7, k, bc)
-    x, _ = _gpu(cpp, mesh, k, ft, G, f, scatter=scatter)
+    x, _ = _gpu(cpp, mesh, k, ft, G, f, scatter=scatter, solver=solver)
     ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f)
     assert np.abs(x - ref).max() <= RTOL * np.abs(ref).max()
 
@@ -87,9 +88,10 @@ def test_multirhs_with_different_bcs(cpp, oracle_mod, k):
     ft = np.stack(fts)
     G = np.stack([d[0] for d in data])
     f = np.stack([d[1] for d in data])
-    x, _ = _gpu(cpp, mesh, k, ft, G, f)
-    ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f)
-    assert np.abs(x - ref).max() <= RTOL * np.abs(ref).max()
+    for solver in (0, 1):
+        x, _ = _gpu(cpp, mesh, k, ft, G, f, solver=solver)
+        ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f)
+        assert np.abs(x - ref).max() <= RTOL * np.abs(ref).max()
 
 
 def test_accumulates_and_is_reproducible(cpp):
@@ -141,8 +143,9 @@ def test_flux_eqlb_se_class(cpp, oracle_mod):
     assert np.abs(sig - ref[0]).max() <= RTOL * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("solver", [0, 1])
 @pytest.mark.parametrize("k,n", [(2, 500), (3, 160)])
-def test_benchmark_size_properties(cpp, k, n):
+def test_benchmark_size_properties(cpp, k, n, solver):
     """At BASELINE.json's size the oracle is too slow for a full comparison: check the
     size-independent properties instead (divergence and jump residuals, linearity,
     oracle agreement on a sample of patches via a node mask)."""
@@ -151,7 +154,7 @@ def test_benchmark_size_properties(cpp, k, n):
     mesh = create_unit_square(n, shuffle_seed=1234)
     ft = facet_types(mesh)
     G, f = make_compatible_data(mesh, k, ft)
-    x, eq = _gpu(cpp, mesh, k, ft, G[None], f[None])
+    x, eq = _gpu(cpp, mesh, k, ft, G[None], f[None], solver=solver)
     res, nrm = chk.divergence_residual(mesh, k, x[0], G, f)
     assert res <= 1e-10 * nrm
     assert chk.jump_residual(mesh, k, x[0], G) <= 1e-9 * np.abs(x).max()
