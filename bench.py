@@ -190,7 +190,7 @@ def main():
 
 
 def eq_solver_name(v):
-    return {None: "lds_cholesky", 0: "lds_cholesky", 1: "shuffle"}[v]
+    return {None: "shuffle", 0: "lds_cholesky", 1: "shuffle", 9: "none(timing only)"}[v]
 
 
 def eq_scatter_name(v):

@@ -224,7 +224,7 @@ int eqlb_se_set_option(eqlb_se_t* h, const char* key, int32_t value)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_set_option: null argument");
   if (!strcmp(key, "solver"))
   {
-    if (value != EQLB_SOLVER_LDS_CHOLESKY && value != EQLB_SOLVER_SHUFFLE)
+    if (value != EQLB_SOLVER_LDS_CHOLESKY && value != EQLB_SOLVER_SHUFFLE && value != 9)
       return fail(EQLB_ERR_INVALID_ARGUMENT, "unknown solver %d", value);
     h->solver = value;
   }
@@ -504,9 +504,13 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
     a.patch_offset = h->bins[b].patch_offset;
     if (evs)
       HIP_TRY(hipEventRecord(evs[2 * b], stream));
-    const int st = eqlb::launch_se_patch(h->k, h->deg, h->bins[b].P, h->solver, h->scatter, a, stream);
-    if (st)
-      return fail(st, "patch kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
+    for (int r = 0; r < h->nrhs; ++r)
+    {
+      a.rhs = r;
+      const int st = eqlb::launch_se_patch(h->k, h->deg, h->bins[b].P, h->solver, h->scatter, a, stream);
+      if (st)
+        return fail(st, "patch kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
+    }
     if (evs)
       HIP_TRY(hipEventRecord(evs[2 * b + 1], stream));
   }

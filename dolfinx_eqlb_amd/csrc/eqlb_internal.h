@@ -63,6 +63,7 @@ struct SeArgs
   int64_t npatch;             // patches of this bin
   int64_t slot_offset, patch_offset, npatch_total;
   int32_t ncells, nrhs;
+  int32_t rhs;                // index of the right-hand side handled by this launch
 };
 
 struct BuildArgs
@@ -108,7 +109,7 @@ struct eqlb_se
   eqlb_mesh* mesh = nullptr;
   int k = 0, deg = 0, nrhs = 0;
   int nrt = 0, nd = 0;
-  int solver = EQLB_SOLVER_LDS_CHOLESKY, scatter = EQLB_SCATTER_SLOTS, timing = 0;
+  int solver = EQLB_SOLVER_SHUFFLE, scatter = EQLB_SCATTER_SLOTS, timing = 0;
   bool boundary_set = false;
   int64_t npatch_total = 0, nslots = 0;
   eqlb::Bin bins[eqlb::MAX_BINS];

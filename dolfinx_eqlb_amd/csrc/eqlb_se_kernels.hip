@@ -44,7 +44,10 @@ __host__ __device__ constexpr double bcoef(int j, int i)
 size_t table_doubles(int k, int deg)
 {
   const int nrt = nrt_of(k), nd = nd_of(deg), nq = nq_of(k);
-  return (size_t)3 * nrt * nrt + (size_t)9 * nd * k + (size_t)3 * nd * nq + (size_t)6 * nd * nq;
+  const int kb = k - 1, nadd = (k - 1) * (k - 2) / 2, ndiv = k * (k + 1) / 2 - 1;
+  const int nh = 1 + 2 * kb + nadd, ncol = 2 * k + ndiv;
+  return (size_t)3 * nrt * nrt + (size_t)9 * nd * k + (size_t)3 * nd * nq + (size_t)6 * nd * nq
+         + (size_t)18 * 3 * (nh * (nh + 1) / 2) + (size_t)18 * 3 * nh * ncol;
 }
 
 template <int K, int DEG>
@@ -56,6 +59,8 @@ static void fill_tables_t(std::vector<double>& out)
   out.insert(out.end(), R::F, R::F + R::F_SIZE);
   out.insert(out.end(), R::H, R::H + R::H_SIZE);
   out.insert(out.end(), R::D, R::D + R::D_SIZE);
+  out.insert(out.end(), R::TE, R::TE + R::TE_SIZE);
+  out.insert(out.end(), R::WQ, R::WQ + R::WQ_SIZE);
 }
 
 int fill_tables_host(int k, int deg, std::vector<double>& out)
@@ -91,6 +96,7 @@ __device__ __forceinline__ double shfl_d(double v, int src_lane) { return __shfl
 
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; } // i >= j
 
+
 // ---- the patch kernel ---------------------------------------------------------------------------
 template <int K, int DEG, int P>
 struct Sizes
@@ -99,43 +105,58 @@ struct Sizes
   static constexpr int NADD = (K - 1) * (K - 2) / 2;
   static constexpr int NDIV = K * (K + 1) / 2 - 1;
   static constexpr int NRT = nrt_of(K), ND = nd_of(DEG), NQ = nq_of(K);
-  static constexpr int NY = 2 * K + NADD;     // own-frame unknowns of a cell: mu_m, mu_p, add
-  static constexpr int NM = NY + NDIV;        // + fixed divergence DOFs
+  static constexpr int NY = 2 * K + NADD;      // own-frame unknowns of a cell: mu_m, mu_p, add
+  static constexpr int NCOL = 2 * K + NDIV;    // columns of the load tensor: mu_m, mu_p, div DOFs
   static constexpr int NH = 1 + 2 * KB + NADD; // local unknowns [d | um | up | ua]
+  static constexpr int NTE = NH * (NH + 1) / 2;
   static constexpr int DIMMAX = 1 + KB * P + NADD * P;
   static constexpr int TRI = DIMMAX * (DIMMAX + 1) / 2;
   static constexpr int LDS_GROUP = TRI + DIMMAX; // doubles per patch for SOLVER 0
+  // device table buffer: S | F | H | D | TE | WQ ; the kernel stages everything behind S in LDS
   static constexpr int NS = 3 * NRT * NRT, NF = 9 * ND * K, NHT = 3 * ND * NQ, NDT = 6 * ND * NQ;
-  static constexpr int NTAB = NS + NF + NHT + NDT;
+  static constexpr int NTET = 18 * 3 * NTE, NWQT = 18 * 3 * NH * NCOL;
+  static constexpr int NTAB = NF + NHT + NDT + NTET + NWQT;
   // workgroup size: as many waves as fit a 64 KiB LDS budget for the dense tiles (at least one)
-  static constexpr int lds_doubles(int block) { return NTAB + (K > 1 ? (block / P) * LDS_GROUP : 0); }
-  static constexpr int BLOCK = (P >= 32) ? 64 : ((lds_doubles(256) * 8 <= 65536) ? 256 : ((lds_doubles(128) * 8 <= 65536) ? 128 : 64));
-  static constexpr int GROUPS = BLOCK / P;
+  static constexpr int lds_doubles(int block, int solver)
+  {
+    return NTAB + ((K > 1 && solver == 0) ? (block / P) * LDS_GROUP : 0);
+  }
+  static constexpr int block_of(int solver)
+  {
+    return (P >= 32) ? 64
+                     : ((lds_doubles(256, solver) * 8 <= 65536)
+                            ? 256
+                            : ((lds_doubles(128, solver) * 8 <= 65536) ? 128 : 64));
+  }
 };
 
 template <int K, int DEG, int P, int SOLVER, int SCATTER>
-__global__ void __launch_bounds__((Sizes<K, DEG, P>::BLOCK)) k_se_patch(const SeArgs a)
+__global__ void __launch_bounds__((Sizes<K, DEG, P>::block_of(SOLVER)))
+    k_se_patch(const SeArgs a)
 {
   using Z = Sizes<K, DEG, P>;
   constexpr int KB = Z::KB, NADD = Z::NADD, NDIV = Z::NDIV, NRT = Z::NRT, ND = Z::ND, NQ = Z::NQ;
-  constexpr int NY = Z::NY, NM = Z::NM, NH = Z::NH;
+  constexpr int NCOL = Z::NCOL, NH = Z::NH, NTE = Z::NTE;
+  constexpr int BLOCK = Z::block_of(SOLVER);
 
   extern __shared__ double lds[];
-  double* sS = lds;            // [3][NRT][NRT]
-  double* sF = sS + Z::NS;     // [3][3][ND][K]
-  double* sH = sF + Z::NF;     // [3][ND][NQ]
-  double* sD = sH + Z::NHT;    // [3][ND][2][NQ]
-  double* sA = sD + Z::NDT;    // SOLVER 0: per-group tiles
+  double* sF = lds;             // [3][3][ND][K]
+  double* sH = sF + Z::NF;      // [3][ND][NQ]
+  double* sD = sH + Z::NHT;     // [3][ND][2][NQ]
+  double* sTE = sD + Z::NDT;    // [18][3][NTE]
+  double* sWQ = sTE + Z::NTET;  // [18][3][NH][NCOL]
+  double* sA = sWQ + Z::NWQT;   // SOLVER 0: per-group tiles
+  (void)sA;
 
   const int tid = threadIdx.x;
-  for (int i = tid; i < Z::NTAB; i += Z::BLOCK)
-    lds[i] = a.tables[i];
+  for (int i = tid; i < Z::NTAB; i += BLOCK)
+    lds[i] = a.tables[Z::NS + i];
   __syncthreads();
 
   const int lane = tid & 63;
   const int sub = lane % P;          // lane within the patch group == cell index i
   const int gbase = lane - sub;      // first lane of the group within the wave
-  const int64_t patch_local = ((int64_t)blockIdx.x * Z::BLOCK + tid) / P;
+  const int64_t patch_local = ((int64_t)blockIdx.x * BLOCK + tid) / P;
   const bool pvalid = patch_local < a.npatch;
   const int64_t slot = a.slot_offset + patch_local * P + sub;
   const int64_t patch = a.patch_offset + patch_local;
@@ -147,6 +168,7 @@ __global__ void __launch_bounds__((Sizes<K, DEG, P>::BLOCK)) k_se_patch(const Se
   const int fm = (info >> INFO_FM_SHIFT) & 3, fp = (info >> INFO_FP_SHIFT) & 3;
   const int ln = (info >> INFO_LN_SHIFT) & 3;
   const bool rev_m = (info & INFO_REV_M) != 0, rev_p = (info & INFO_REV_P) != 0;
+  const int ci = (fm * 3 + fp) * 2 + (rev_m ? 1 : 0); // row of the reduced tensors
 
   // ---- geometry (cached affine map) ----
   double J00 = 1.0, J01 = 0.0, J10 = 0.0, J11 = 1.0;
@@ -160,114 +182,9 @@ __global__ void __launch_bounds__((Sizes<K, DEG, P>::BLOCK)) k_se_patch(const Se
     J11 = j1.y;
   }
   const double detJ = J00 * J11 - J01 * J10;
-  const double adet = fabs(detJ), sgn = (detJ > 0.0) ? 1.0 : -1.0;
-  // adj[X][d] = detJ * K[X][d]
-  const double a00 = J11, a01 = -J01, a10 = -J10, a11 = J00;
+  const double sgn = (detJ > 0.0) ? 1.0 : -1.0;
   const double pf_m = (fm == 1) ? sgn : -sgn; // facet 1 measures the outward flux
   const double pf_p = (fp == 1) ? sgn : -sgn;
-  // nu_f = adj^T N_f, N = {(-1,-1), (-1,0), (0,1)}
-  const double nmx = (fm == 2) ? 0.0 : -1.0, nmy = (fm == 0) ? -1.0 : ((fm == 1) ? 0.0 : 1.0);
-  const double npx = (fp == 2) ? 0.0 : -1.0, npy = (fp == 0) ? -1.0 : ((fp == 1) ? 0.0 : 1.0);
-  const double num0 = a00 * nmx + a10 * nmy, num1 = a01 * nmx + a11 * nmy;
-  const double nup0 = a00 * npx + a10 * npy, nup1 = a01 * npx + a11 * npy;
-
-  // ---- element mass matrix in own-frame unknowns: My = s (g00 S0 + g01 S1 + g11 S2) s / |detJ|
-  const double ia = 1.0 / adet;
-  const double g00 = (J00 * J00 + J10 * J10) * ia, g01 = (J00 * J01 + J10 * J11) * ia,
-               g11 = (J01 * J01 + J11 * J11) * ia;
-  int idx[NM];
-  double sg[NM];
-#pragma unroll
-  for (int j = 0; j < K; ++j)
-  {
-    idx[j] = fm * K + j;
-    sg[j] = pf_m;
-    idx[K + j] = fp * K + j;
-    sg[K + j] = pf_p;
-  }
-#pragma unroll
-  for (int q = 0; q < NADD; ++q)
-  {
-    idx[2 * K + q] = 3 * K + NDIV + q;
-    sg[2 * K + q] = 1.0;
-  }
-#pragma unroll
-  for (int q = 0; q < NDIV; ++q)
-  {
-    idx[NY + q] = 3 * K + q;
-    sg[NY + q] = 1.0;
-  }
-  double My[NY][NM];
-#pragma unroll
-  for (int r = 0; r < NY; ++r)
-#pragma unroll
-    for (int c = 0; c < NM; ++c)
-    {
-      const int o = idx[r] * NRT + idx[c];
-      My[r][c] = sg[r] * sg[c] * (g00 * sS[o] + g01 * sS[NRT * NRT + o] + g11 * sS[2 * NRT * NRT + o]);
-    }
-
-  // ---- local minimisation matrix Te = Q^T My Q  (Q maps [d|um|up|ua] to own-frame moments)
-  // minus block: mu_m += -Bm [d; um], Bm = B (reversed facet) or I
-  double Qm[K][K];
-#pragma unroll
-  for (int j = 0; j < K; ++j)
-#pragma unroll
-    for (int c = 0; c < K; ++c)
-      Qm[j][c] = -(rev_m ? bcoef(j, c) : ((j == c) ? 1.0 : 0.0));
-  // column of local unknown h in own-frame space (NY)
-  auto qcol = [&](int h, double* col) {
-#pragma unroll
-    for (int r = 0; r < NY; ++r)
-      col[r] = 0.0;
-    if (h == 0)
-    {
-#pragma unroll
-      for (int j = 0; j < K; ++j)
-        col[j] = Qm[j][0];
-      col[K] = 1.0;
-    }
-    else if (h <= KB)
-    {
-#pragma unroll
-      for (int j = 0; j < K; ++j)
-        col[j] = Qm[j][h];
-    }
-    else if (h <= 2 * KB)
-      col[K + (h - KB)] = 1.0;
-    else
-      col[2 * K + (h - 1 - 2 * KB)] = 1.0;
-  };
-  double Qc[NH][NY];
-#pragma unroll
-  for (int h = 0; h < NH; ++h)
-    qcol(h, Qc[h]);
-  double Te[NH][NH];
-  {
-    double T1[NH][NY]; // (My_yy Q)^T
-#pragma unroll
-    for (int h = 0; h < NH; ++h)
-#pragma unroll
-      for (int r = 0; r < NY; ++r)
-      {
-        double s = 0.0;
-#pragma unroll
-        for (int c = 0; c < NY; ++c)
-          s += My[r][c] * Qc[h][c];
-        T1[h][r] = s;
-      }
-#pragma unroll
-    for (int h = 0; h < NH; ++h)
-#pragma unroll
-      for (int g = 0; g < NH; ++g)
-      {
-        double s = 0.0;
-#pragma unroll
-        for (int r = 0; r < NY; ++r)
-          s += Qc[h][r] * T1[g][r];
-        Te[h][g] = active ? s : 0.0;
-      }
-  }
 
   // ---- neighbour lanes ----
   const uint8_t flag0 = pvalid ? a.pflag[patch] : (uint8_t)PFLAG_INTERIOR;
@@ -278,126 +195,121 @@ __global__ void __launch_bounds__((Sizes<K, DEG, P>::BLOCK)) k_se_patch(const Se
   const int prev = (sub > 0) ? sub - 1 : (interior_geo ? nn - 1 : 0);
   const bool has_next = active && (interior_geo || sub < n - 1);
   const bool has_prev = active && (interior_geo || sub > 0);
-
-  // global unknown numbers of the local unknowns (SOLVER 0)
   const int fi_p = interior_geo ? ((sub + 1 < nn) ? sub + 1 : 0) : sub + 1;
   const int dim = pvalid ? 1 + KB * nf + NADD * n : 0;
+  (void)dim;
 
   int status_local = 0;
 
-  for (int r = 0; r < a.nrhs; ++r)
+  // one right-hand side per launch (a.rhs): a loop over the RHS here makes the compiler hoist the
+  // ~70 loop-invariant table loads of phase C above the loop and hold them in ~140 VGPRs
+  const int r = a.rhs;
   {
     const uint8_t flag = pvalid ? a.pflag[(int64_t)r * a.npatch_total + patch] : (uint8_t)0;
     const bool bc0 = (flag & PFLAG_BC0) != 0, bcn = (flag & PFLAG_BCN) != 0;
-
-    // ---- load the cell data ----
-    double G[ND][2], fv[ND];
-    if (active)
-    {
-      const double* gp_ = a.flux_dg + ((int64_t)r * a.ncells + cell) * (ND * 2);
-      const double* fp_ = a.rhs_dg + ((int64_t)r * a.ncells + cell) * ND;
-#pragma unroll
-      for (int i = 0; i < ND; ++i)
-      {
-        const double2 g2 = reinterpret_cast<const double2*>(gp_)[i];
-        G[i][0] = g2.x;
-        G[i][1] = g2.y;
-        fv[i] = fp_[i];
-      }
-    }
-    else
-    {
-#pragma unroll
-      for (int i = 0; i < ND; ++i)
-        G[i][0] = G[i][1] = fv[i] = 0.0;
-    }
-
-    // ---- cell-local integrals: facet moments of hat*G, moments of hat*(f - div G) ----
-    double gm[K], gpv[K], Rq[NQ];
-#pragma unroll
-    for (int j = 0; j < K; ++j)
-      gm[j] = gpv[j] = 0.0;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-      Rq[q] = 0.0;
-#pragma unroll
-    for (int i = 0; i < ND; ++i)
-    {
-      const double gnm = G[i][0] * num0 + G[i][1] * num1;
-      const double gnp = G[i][0] * nup0 + G[i][1] * nup1;
-      const double gh0 = a00 * G[i][0] + a01 * G[i][1]; // (adj G_i)_X
-      const double gh1 = a10 * G[i][0] + a11 * G[i][1];
-#pragma unroll
-      for (int j = 0; j < K; ++j)
-      {
-        gm[j] += sF[((fm * 3 + ln) * ND + i) * K + j] * gnm;
-        gpv[j] += sF[((fp * 3 + ln) * ND + i) * K + j] * gnp;
-      }
-#pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        Rq[q] += detJ * fv[i] * sH[(ln * ND + i) * NQ + q] - gh0 * sD[((ln * ND + i) * 2 + 0) * NQ + q]
-                 - gh1 * sD[((ln * ND + i) * 2 + 1) * NQ + q];
-    }
-#pragma unroll
-    for (int j = 0; j < K; ++j)
-    {
-      gm[j] *= pf_m;
-      gpv[j] *= pf_p;
-    }
-    const double R0 = sgn * Rq[0];
-
-    // ---- jump moments on the plus facet (owner frame) ----
-    double Jv[K];
-    {
-      double gmn[K];
-#pragma unroll
-      for (int j = 0; j < K; ++j)
-        gmn[j] = shfl_d(gm[j], gbase + next);
-#pragma unroll
-      for (int j = 0; j < K; ++j)
-      {
-        double t = 0.0;
-        if (rev_p)
-        {
-#pragma unroll
-          for (int i = 0; i < K; ++i)
-            t += bcoef(j, i) * gmn[i];
-        }
-        else
-          t = gmn[j];
-        Jv[j] = has_next ? gpv[j] + t : 0.0;
-      }
-    }
-
-    // ---- zero-order chain: inclusive prefix sum of R0 + J0(previous facet) ----
-    const double Jprev0 = shfl_d(Jv[0], gbase + prev);
-    double t = active ? (R0 + (has_prev ? Jprev0 : 0.0)) : 0.0;
-#pragma unroll
-    for (int off = 1; off < P; off <<= 1)
-    {
-      const double o = shfl_d(t, gbase + ((sub >= off) ? sub - off : sub));
-      if (sub >= off)
-        t += o;
-    }
-    double delta = 0.0;
-    {
-      const double gm0_first = shfl_d(gm[0], gbase);
-      const double gp0_last = shfl_d(gpv[0], gbase + nn - 1);
-      const double t_last = shfl_d(t, gbase + nn - 1);
-      if (bc0)
-        delta = gm0_first;
-      else if (bcn)
-        delta = -gp0_last - t_last;
-    }
     const bool d_fixed = bc0 || bcn;
 
-    // ---- particular solution (own-frame outward moments) ----
-    double mu_p[K], mu_m[K];
-    mu_p[0] = t + delta;
-#pragma unroll
-    for (int j = 1; j < K; ++j)
-      mu_p[j] = (bcn && sub == n - 1) ? -gpv[j] : 0.0;
+    // ---- phase A: cell-local integrals: facet moments of hat*G, moments of hat*(f - div G) ----
+    // full[] collects the particular solution in the load-tensor column order
+    // [mu_m (K) | mu_p (K) | sgn * c_div (NDIV)]
+    double gm[K], gpv[K], Rq[NQ];
     {
+      // adj[X][d] = detJ * K[X][d];  nu_f = adj^T N_f, N = {(-1,-1), (-1,0), (0,1)}
+      const double a00 = J11, a01 = -J01, a10 = -J10, a11 = J00;
+      const double nmx = (fm == 2) ? 0.0 : -1.0, nmy = (fm == 0) ? -1.0 : ((fm == 1) ? 0.0 : 1.0);
+      const double npx = (fp == 2) ? 0.0 : -1.0, npy = (fp == 0) ? -1.0 : ((fp == 1) ? 0.0 : 1.0);
+      const double num0 = a00 * nmx + a10 * nmy, num1 = a01 * nmx + a11 * nmy;
+      const double nup0 = a00 * npx + a10 * npy, nup1 = a01 * npx + a11 * npy;
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+        gm[j] = gpv[j] = 0.0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        Rq[q] = 0.0;
+      if (active)
+      {
+        const double2* gp_ = reinterpret_cast<const double2*>(a.flux_dg + ((int64_t)r * a.ncells + cell) * (ND * 2));
+        const double* fp_ = a.rhs_dg + ((int64_t)r * a.ncells + cell) * ND;
+        const double* tF_m = sF + (fm * 3 + ln) * ND * K;
+        const double* tF_p = sF + (fp * 3 + ln) * ND * K;
+        const double* tH = sH + ln * ND * NQ;
+        const double* tD = sD + ln * ND * 2 * NQ;
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+        {
+          const double2 g2 = gp_[i];
+          const double fv = fp_[i];
+          const double gnm = g2.x * num0 + g2.y * num1;
+          const double gnp = g2.x * nup0 + g2.y * nup1;
+          const double gh0 = a00 * g2.x + a01 * g2.y; // (adj G_i)_X
+          const double gh1 = a10 * g2.x + a11 * g2.y;
+          const double fd = detJ * fv;
+#pragma unroll
+          for (int j = 0; j < K; ++j)
+          {
+            gm[j] += tF_m[i * K + j] * gnm;
+            gpv[j] += tF_p[i * K + j] * gnp;
+          }
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            Rq[q] += fd * tH[i * NQ + q] - gh0 * tD[(i * 2 + 0) * NQ + q] - gh1 * tD[(i * 2 + 1) * NQ + q];
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+        {
+          gm[j] *= pf_m;
+          gpv[j] *= pf_p;
+        }
+      }
+    }
+
+    // ---- phase B: neighbour exchange -> particular solution in own-frame outward moments ----
+    double mu_m[K], mu_p[K];
+    {
+      // jump moments on the plus facet (owner frame)
+      double Jv[K];
+      {
+        double gmn[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+          gmn[j] = shfl_d(gm[j], gbase + next);
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+        {
+          double t = 0.0;
+          if (rev_p)
+          {
+#pragma unroll
+            for (int i = 0; i < K; ++i)
+              t += bcoef(j, i) * gmn[i];
+          }
+          else
+            t = gmn[j];
+          Jv[j] = has_next ? gpv[j] + t : 0.0;
+        }
+      }
+      // zero-order chain: inclusive prefix sum of R0 + J0(previous facet)
+      const double Jprev0 = shfl_d(Jv[0], gbase + prev);
+      double t = active ? (sgn * Rq[0] + (has_prev ? Jprev0 : 0.0)) : 0.0;
+#pragma unroll
+      for (int off = 1; off < P; off <<= 1)
+      {
+        const double o = shfl_d(t, gbase + ((sub >= off) ? sub - off : sub));
+        if (sub >= off)
+          t += o;
+      }
+      double delta = 0.0;
+      if (d_fixed)
+      {
+        const double gm0_first = shfl_d(gm[0], gbase);
+        const double gp0_last = shfl_d(gpv[0], gbase + nn - 1);
+        const double t_last = shfl_d(t, gbase + nn - 1);
+        delta = bc0 ? gm0_first : (-gp0_last - t_last);
+      }
+      mu_p[0] = t + delta;
+#pragma unroll
+      for (int j = 1; j < K; ++j)
+        mu_p[j] = (bcn && sub == n - 1) ? -gpv[j] : 0.0;
       double vprev[K];
 #pragma unroll
       for (int j = 0; j < K; ++j)
@@ -410,7 +322,7 @@ __global__ void __launch_bounds__((Sizes<K, DEG, P>::BLOCK)) k_se_patch(const Se
           double s = 0.0;
 #pragma unroll
           for (int c = 0; c < K; ++c)
-            s += Qm[j][c] * vprev[c];
+            s -= (rev_m ? bcoef(j, c) : ((j == c) ? 1.0 : 0.0)) * vprev[c];
           mu_m[j] = s;
         }
       }
@@ -423,40 +335,47 @@ __global__ void __launch_bounds__((Sizes<K, DEG, P>::BLOCK)) k_se_patch(const Se
       }
     }
 
-    // ---- load vector Le = -Q^T My [ytil; c_div] ----
-    double full[NM];
-#pragma unroll
-    for (int j = 0; j < K; ++j)
+    // ---- phase C: element matrix and load from the reduced reference tensors ----
+    // Te = sum_x g_x TE[ci][x], Le = -sum_x g_x WQ[ci][x] [mu_m; mu_p; sgn c_div], g = J^T J/|detJ|
+    double Te[NH][NH], Le[NH];
     {
-      full[j] = mu_m[j];
-      full[K + j] = mu_p[j];
-    }
+      const double ia = active ? 1.0 / fabs(detJ) : 0.0;
+      const double g0 = (J00 * J00 + J10 * J10) * ia, g1 = (J00 * J01 + J10 * J11) * ia,
+                   g2 = (J01 * J01 + J11 * J11) * ia;
+      const double* te = sTE + ci * 3 * NTE;
 #pragma unroll
-    for (int q = 0; q < NADD; ++q)
-      full[2 * K + q] = 0.0;
+      for (int h = 0; h < NH; ++h)
 #pragma unroll
-    for (int q = 0; q < NDIV; ++q)
-      full[NY + q] = Rq[1 + q];
-    double Le[NH];
-    {
-      double w[NY];
+        for (int g = 0; g <= h; ++g)
+        {
+          const int e = h * (h + 1) / 2 + g;
+          const double v = g0 * te[e] + g1 * te[NTE + e] + g2 * te[2 * NTE + e];
+          Te[h][g] = v;
+          Te[g][h] = v;
+        }
+      double full[NCOL];
 #pragma unroll
-      for (int rr = 0; rr < NY; ++rr)
+      for (int j = 0; j < K; ++j)
       {
-        double s = 0.0;
-#pragma unroll
-        for (int c = 0; c < NM; ++c)
-          s += My[rr][c] * full[c];
-        w[rr] = s;
+        full[j] = mu_m[j];
+        full[K + j] = mu_p[j];
       }
+#pragma unroll
+      for (int q = 0; q < NDIV; ++q)
+        full[2 * K + q] = sgn * Rq[1 + q];
+      const double* wq = sWQ + ci * 3 * NH * NCOL;
 #pragma unroll
       for (int h = 0; h < NH; ++h)
       {
-        double s = 0.0;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
-        for (int rr = 0; rr < NY; ++rr)
-          s += Qc[h][rr] * w[rr];
-        Le[h] = active ? -s : 0.0;
+        for (int c = 0; c < NCOL; ++c)
+        {
+          s0 += wq[h * NCOL + c] * full[c];
+          s1 += wq[(NH + h) * NCOL + c] * full[c];
+          s2 += wq[(2 * NH + h) * NCOL + c] * full[c];
+        }
+        Le[h] = -(g0 * s0 + g1 * s1 + g2 * s2);
       }
     }
 
@@ -473,6 +392,13 @@ __global__ void __launch_bounds__((Sizes<K, DEG, P>::BLOCK)) k_se_patch(const Se
         sl += shfl_d(sl, gbase + (sub ^ off));
       }
       ul[0] = (d_fixed || !pvalid) ? 0.0 : sl / sa;
+    }
+    else if constexpr (SOLVER == 9)
+    {
+      // timing-only build (results are wrong): no solve, to price the solver
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+        ul[h] = Le[h] + Te[h][0];
     }
     else if constexpr (SOLVER == 0)
     {
@@ -993,32 +919,36 @@ __global__ void __launch_bounds__((Sizes<K, DEG, P>::BLOCK)) k_se_patch(const Se
       }
     }
 
-    // ---- back-map to RT coefficients and scatter ----
+
+    // ---- phase E: back-map to RT coefficients (se/solve_patch_semiexplt.hpp:1082-1153) ----
     if (active)
     {
-      double y[NY];
+      // own-frame moments: mu_m -= Bm [d; um], mu_p += [d; up]
+      double ym[K], yp[K];
 #pragma unroll
-      for (int rr = 0; rr < NY; ++rr)
+      for (int j = 0; j < K; ++j)
       {
-        double s = full[rr];
+        double s = mu_m[j];
 #pragma unroll
-        for (int h = 0; h < NH; ++h)
-          s += Qc[h][rr] * ul[h];
-        y[rr] = s;
+        for (int c = 0; c < K; ++c)
+          s -= (rev_m ? bcoef(j, c) : ((j == c) ? 1.0 : 0.0)) * ul[c]; // ul[0] = d, ul[1..KB] = um
+        ym[j] = s;
+        yp[j] = mu_p[j] + ((j == 0) ? ul[0] : ul[KB + j]);
       }
       double cout[NRT];
 #pragma unroll
       for (int e = 0; e < 3 * K; ++e)
       {
         const int fe = e / K, j = e % K;
-        cout[e] = (fe == fm) ? pf_m * y[j] : ((fe == fp) ? pf_p * y[K + j] : 0.0);
+        cout[e] = (fe == fm) ? pf_m * ym[j] : ((fe == fp) ? pf_p * yp[j] : 0.0);
       }
 #pragma unroll
       for (int q = 0; q < NDIV; ++q)
         cout[3 * K + q] = Rq[1 + q];
 #pragma unroll
       for (int q = 0; q < NADD; ++q)
-        cout[3 * K + NDIV + q] = y[2 * K + q];
+        cout[3 * K + NDIV + q] = sgn * ul[1 + 2 * KB + q]; // interior unknowns are scaled by sign(detJ),
+                                                          // so that the tensors TE/WQ carry no sign
 
       if constexpr (SCATTER == 0)
       {
@@ -1074,8 +1004,8 @@ template <int K, int DEG, int P, int SOLVER, int SCATTER>
 static int launch_t(const SeArgs& a, hipStream_t stream)
 {
   using Z = Sizes<K, DEG, P>;
-  const size_t lds_bytes
-      = sizeof(double) * ((size_t)Z::NTAB + ((SOLVER == 0 && K > 1) ? (size_t)Z::GROUPS * Z::LDS_GROUP : 0));
+  constexpr int BLOCK = Z::block_of(SOLVER);
+  const size_t lds_bytes = sizeof(double) * (size_t)Z::lds_doubles(BLOCK, SOLVER);
   if (lds_bytes > 160 * 1024)
     return EQLB_ERR_UNSUPPORTED;
   auto kern = k_se_patch<K, DEG, P, SOLVER, SCATTER>;
@@ -1087,10 +1017,10 @@ static int launch_t(const SeArgs& a, hipStream_t stream)
       return EQLB_ERR_DEVICE;
   }
   const int64_t nthreads = a.npatch * P;
-  const int64_t grid = (nthreads + Z::BLOCK - 1) / Z::BLOCK;
+  const int64_t grid = (nthreads + BLOCK - 1) / BLOCK;
   if (grid == 0)
     return 0;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Z::BLOCK), lds_bytes, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds_bytes, stream, a);
   return (hipGetLastError() == hipSuccess) ? 0 : EQLB_ERR_DEVICE;
 }
 
@@ -1116,6 +1046,8 @@ static int launch_p(int P, const SeArgs& a, hipStream_t stream)
 template <int K, int DEG>
 static int launch_kd(int P, int solver, int scatter, const SeArgs& a, hipStream_t stream)
 {
+  if (solver == 9)
+    return launch_p<K, DEG, 9, 0>(P, a, stream);
   if (solver == EQLB_SOLVER_SHUFFLE)
   {
     if (scatter == EQLB_SCATTER_SLOTS)

@@ -67,7 +67,67 @@ def tables_exact(k, deg):
                 D[n][i][0][q] = P.integrate_triangle(P.mul(P.ddx(dg.basis[i]), w))
                 D[n][i][1][q] = P.integrate_triangle(P.mul(P.ddy(dg.basis[i]), w))
     B = [[Fraction(comb(j, i) * (-1) ** i) for i in range(k)] for j in range(k)]
-    return dict(k=k, deg=deg, nrt=nrt, nd=nd, nq=len(monos), S=S, F=F, H=H, D=D, B=B)
+    TE, WQ = reduced_tensors(k, S, B)
+    return dict(k=k, deg=deg, nrt=nrt, nd=nd, nq=len(monos), S=S, F=F, H=H, D=D, B=B, TE=TE, WQ=WQ)
+
+
+def reduced_tensors(k, S, B):
+    """Element matrices of the patch-wise H(div=0) functions, per combination
+    ci = (fm*3 + fp)*2 + rev of the local ids of the two patch facets of a cell and the
+    reversal flag of the minus facet, for the three metric components x:
+
+      TE[ci][x][h(h+1)/2+g] = (Q^T D0 S_x D0 Q)_{hg}          local unknowns [d | um | up | ua]
+      WQ[ci][x][h][c]       = (Q^T D0 S_x [D0 | I])_{hc}      columns [mu_m | mu_p | div DOFs]
+
+    with S_x restricted to the DOFs [minus facet | plus facet | interior | div], D0 the signs
+    turning outward flux moments into RT coefficients (up to sign(detJ), which cancels), and Q
+    the map of se/fluxmin_kernel.hpp:107-138 (d0 function, reversed-facet transformation) in the
+    own-frame formulation: mu_m += -Bm [d; um], mu_p += [d; up].
+    element matrix = sum_x g_x TE_x, g = J^T J / |detJ|;  load = -sum_x g_x WQ_x [mu_m; mu_p; s c_div].
+    """
+    kb = k - 1
+    nadd = (k - 1) * (k - 2) // 2
+    ndiv = k * (k + 1) // 2 - 1
+    ny, nh = 2 * k + nadd, 1 + 2 * kb + nadd
+    ncol = 2 * k + ndiv
+    nte = nh * (nh + 1) // 2
+    zero = Fraction(0)
+    TE = [[[zero] * nte for _ in range(3)] for _ in range(18)]
+    WQ = [[[[zero] * ncol for _ in range(nh)] for _ in range(3)] for _ in range(18)]
+    for fm in range(3):
+        for fp in range(3):
+            if fm == fp:
+                continue
+            idx = [fm * k + j for j in range(k)] + [fp * k + j for j in range(k)] \
+                + [3 * k + ndiv + q for q in range(nadd)] + [3 * k + q for q in range(ndiv)]
+            sm = 1 if ert.FACET_NORMAL_IS_OUTWARD[fm] else -1
+            sp = 1 if ert.FACET_NORMAL_IS_OUTWARD[fp] else -1
+            d0 = [sm] * k + [sp] * k + [1] * nadd
+            for rev in range(2):
+                ci = (fm * 3 + fp) * 2 + rev
+                Q = [[zero] * nh for _ in range(ny)]
+                for j in range(k):
+                    for c in range(k):
+                        bm = B[j][c] if rev else Fraction(int(j == c))
+                        Q[j][c] = -bm  # local unknown c: 0 = d, 1..kb = um
+                Q[k][0] = Fraction(1)
+                for j in range(1, k):
+                    Q[k + j][kb + j] = Fraction(1)
+                for q in range(nadd):
+                    Q[2 * k + q][1 + 2 * kb + q] = Fraction(1)
+                for x in range(3):
+                    M = [[S[x][idx[r]][idx[c]] for c in range(len(idx))] for r in range(ny)]
+                    # A = D0 M_yy D0 ; columns of the load: [mu_m | mu_p | div]
+                    cols = list(range(2 * k)) + list(range(ny, ny + ndiv))
+                    dcol = d0[:2 * k] + [1] * ndiv
+                    DM = [[d0[r] * M[r][c] for c in range(len(idx))] for r in range(ny)]
+                    for h in range(nh):
+                        for cc, c in enumerate(cols):
+                            WQ[ci][x][h][cc] = sum(Q[r][h] * DM[r][c] * dcol[cc] for r in range(ny))
+                        for g in range(h + 1):
+                            TE[ci][x][h * (h + 1) // 2 + g] = sum(
+                                Q[r][h] * DM[r][c] * d0[c] * Q[c][g] for r in range(ny) for c in range(ny))
+    return TE, WQ
 
 
 def _flat(x):
@@ -83,7 +143,7 @@ def tables_float(k, deg):
     import numpy as np
     t = tables_exact(k, deg)
     out = dict(k=k, deg=deg, nrt=t["nrt"], nd=t["nd"], nq=t["nq"])
-    for name in "SFHDB":
+    for name in ("S", "F", "H", "D", "B", "TE", "WQ"):
         def shape(x):
             return (len(x),) + shape(x[0]) if isinstance(x, list) else ()
         out[name] = np.array([float(v) for v in _flat(t[name])]).reshape(shape(t[name]))
@@ -117,6 +177,10 @@ def emit(path):
         arr("H", (3, nd, nq), t["H"])
         arr("D", (3, nd, 2, nq), t["D"])
         arr("B", (k, k), t["B"])
+        kb_, nadd_, ndiv_ = k - 1, (k - 1) * (k - 2) // 2, k * (k + 1) // 2 - 1
+        nh_ = 1 + 2 * kb_ + nadd_
+        arr("TE", (18, 3, nh_ * (nh_ + 1) // 2), t["TE"])
+        arr("WQ", (18, 3, nh_, 2 * k + ndiv_), t["WQ"])
         lines.append("};")
         lines.append("")
     lines.append("// reference facet normals of the RT functionals (e_raviart_thomas.py:82) and whether the")
