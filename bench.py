@@ -168,7 +168,7 @@ def main():
             "bound": "hbm",
             "kernel": f"k_se_patch<K={k},P={4 << dom}>",
             "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-            "traffic": None,
+            "traffic": measured_traffic(f"k_se_patch<K={k},P={4 << dom}>") if n == 500 and world == 1 else None,
             "algorithmic_bytes_per_launch": alg_bytes,
             "kernel_ms": bins_ms[dom],
             "all_kernels_ms": {f"patch_P{4 << b}": bins_ms[b] for b in range(5) if bins_ms[b] > 0}
@@ -187,6 +187,16 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json);
+    PMC counters cannot be read from inside the process."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            return json.load(fh).get(kernel)
+    except OSError:
+        return None
 
 
 def eq_solver_name(v):
