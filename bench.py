@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--k", type=int, default=2, help="RT degree")
     ap.add_argument("--solver", type=int, default=None)
     ap.add_argument("--scatter", type=int, default=None)
+    ap.add_argument("--fused", type=int, default=1, help="all patch-size bins in one launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shuffle", type=int, default=None, help="seed for random local vertex order")
     return ap.parse_args()
@@ -83,6 +84,8 @@ def main():
         eq.set_option("solver", args.solver)
     if args.scatter is not None:
         eq.set_option("scatter", args.scatter)
+    fused = bool(args.fused) and args.solver in (None, 1)
+    eq.set_option("fused", int(fused))
     eq.set_boundary(ft, node_mask=part.node_mask)
     npatch_local = eq.num_patches
 
@@ -140,7 +143,14 @@ def main():
     dom = int(np.argmax(bins_ms))
     total_pc = float(sum(ncells_bin))
     bytes_sweep = compulsory_bytes_per_cell(k, 1) * part.ncells_owned
-    alg_bytes = bytes_sweep * ncells_bin[dom] / total_pc  # share of the sweep done by that launch
+    if fused:  # one launch does the whole sweep
+        alg_bytes = float(bytes_sweep)
+        kname = f"k_se_patch_fused<K={k}>"
+        kernels_ms = {kname: bins_ms[0]}
+    else:      # share of the sweep done by the dominant bin's launch
+        alg_bytes = bytes_sweep * ncells_bin[dom] / total_pc
+        kname = f"k_se_patch<K={k},P={4 << dom}>"
+        kernels_ms = {f"patch_P{4 << b}": bins_ms[b] for b in range(5) if bins_ms[b] > 0}
     achieved = alg_bytes / (bins_ms[dom] * 1e-3) / 1e9 if bins_ms[dom] > 0 else 0.0
     peak = 8000.0
 
@@ -166,13 +176,12 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": f"k_se_patch<K={k},P={4 << dom}>",
+            "kernel": kname,
             "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-            "traffic": measured_traffic(f"k_se_patch<K={k},P={4 << dom}>") if n == 500 and world == 1 else None,
+            "traffic": measured_traffic(kname) if n == 500 and world == 1 else None,
             "algorithmic_bytes_per_launch": alg_bytes,
             "kernel_ms": bins_ms[dom],
-            "all_kernels_ms": {f"patch_P{4 << b}": bins_ms[b] for b in range(5) if bins_ms[b] > 0}
-            | ({"reduce_slots": reduce_ms} if reduce_ms > 0 else {}),
+            "all_kernels_ms": kernels_ms | ({"reduce_slots": reduce_ms} if reduce_ms > 0 else {}),
         },
     }
     if res is not None:

@@ -234,6 +234,8 @@ int eqlb_se_set_option(eqlb_se_t* h, const char* key, int32_t value)
       return fail(EQLB_ERR_INVALID_ARGUMENT, "unknown scatter mode %d", value);
     h->scatter = value;
   }
+  else if (!strcmp(key, "fused"))
+    h->fused = value;
   else if (!strcmp(key, "timing"))
   {
     h->timing = value;
@@ -495,6 +497,33 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
   a.ncells = m.ncells;
   a.nrhs = h->nrhs;
 
+  if (h->fused && h->solver == EQLB_SOLVER_SHUFFLE)
+  {
+    // all bins in one launch; timing slot 0 holds the fused kernel
+    eqlb::FusedBins fb{};
+    int64_t nb = 0;
+    for (int b = 0; b < eqlb::MAX_BINS; ++b)
+    {
+      fb.block_start[b] = nb;
+      fb.npatch[b] = h->bins[b].npatch;
+      fb.slot_offset[b] = h->bins[b].slot_offset;
+      fb.patch_offset[b] = h->bins[b].patch_offset;
+      nb += (h->bins[b].npatch * h->bins[b].P + 255) / 256;
+    }
+    fb.block_start[eqlb::MAX_BINS] = nb;
+    for (int r = 0; r < h->nrhs; ++r)
+    {
+      a.rhs = r;
+      if (evs && r == 0)
+        HIP_TRY(hipEventRecord(evs[0], stream));
+      const int st = eqlb::launch_se_patch_fused(h->k, h->deg, h->scatter, a, fb, stream);
+      if (st)
+        return fail(st, "fused patch kernel launch failed (k=%d)", h->k);
+    }
+    if (evs)
+      HIP_TRY(hipEventRecord(evs[1], stream));
+  }
+  else
   for (int b = 0; b < eqlb::MAX_BINS; ++b)
   {
     if (h->bins[b].npatch == 0)
@@ -548,7 +577,8 @@ double eqlb_se_last_kernel_ms(const eqlb_se_t* h, int32_t which)
   // (at most the last EV_RING calls).  Synchronises with the recorded events.
   if (!h || !h->ev || h->ev_calls == 0 || which < 0 || which > eqlb::MAX_BINS)
     return 0.0;
-  if (which < eqlb::MAX_BINS && h->bins[which].npatch == 0)
+  const bool fused_run = h->fused && h->solver == EQLB_SOLVER_SHUFFLE;
+  if (which < eqlb::MAX_BINS && ((fused_run && which != 0) || (!fused_run && h->bins[which].npatch == 0)))
     return 0.0;
   if (which == eqlb::MAX_BINS && h->scatter != EQLB_SCATTER_SLOTS)
     return 0.0;

@@ -66,6 +66,13 @@ struct SeArgs
   int32_t rhs;                // index of the right-hand side handled by this launch
 };
 
+// bins of a fused launch: blocks [block_start[b], block_start[b+1]) of 256 threads handle bin b
+struct FusedBins
+{
+  int64_t block_start[MAX_BINS + 1];
+  int64_t npatch[MAX_BINS], slot_offset[MAX_BINS], patch_offset[MAX_BINS];
+};
+
 struct BuildArgs
 {
   int32_t nnodes, nfacets, nrhs;
@@ -92,6 +99,8 @@ void launch_cell_geometry(int32_t ncells, const double* x, const int32_t* cell_n
 // returns 0 or EQLB_ERR_UNSUPPORTED
 int launch_se_patch(int k, int deg, int P, int solver, int scatter, const SeArgs& a,
                     hipStream_t stream);
+int launch_se_patch_fused(int k, int deg, int scatter, const SeArgs& a, const FusedBins& fb,
+                          hipStream_t stream);
 void launch_reduce_slots(int nrt, int32_t ncells, int32_t nrhs, const double* slots, double* x,
                          hipStream_t stream);
 size_t table_doubles(int k, int deg);
@@ -109,7 +118,7 @@ struct eqlb_se
   eqlb_mesh* mesh = nullptr;
   int k = 0, deg = 0, nrhs = 0;
   int nrt = 0, nd = 0;
-  int solver = EQLB_SOLVER_SHUFFLE, scatter = EQLB_SCATTER_SLOTS, timing = 0;
+  int solver = EQLB_SOLVER_SHUFFLE, scatter = EQLB_SCATTER_SLOTS, timing = 0, fused = 1;
   bool boundary_set = false;
   int64_t npatch_total = 0, nslots = 0;
   eqlb::Bin bins[eqlb::MAX_BINS];

@@ -97,6 +97,15 @@ __device__ __forceinline__ double shfl_d(double v, int src_lane) { return __shfl
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; } // i >= j
 
 
+// A/B switches of the memory path: cooperative LDS staging of the input
+// rows (LDS-DMA) and of the output slot rows
+#ifndef EQLB_STAGE_IN
+#define EQLB_STAGE_IN 0
+#endif
+#ifndef EQLB_STAGE_OUT
+#define EQLB_STAGE_OUT 0
+#endif
+
 // ---- the patch kernel ---------------------------------------------------------------------------
 template <int K, int DEG, int P>
 struct Sizes
@@ -117,9 +126,15 @@ struct Sizes
   static constexpr int NTET = 18 * 3 * NTE, NWQT = 18 * 3 * NH * NCOL;
   static constexpr int NTAB = NF + NHT + NDT + NTET + NWQT;
   // workgroup size: as many waves as fit a 64 KiB LDS budget for the dense tiles (at least one)
+  // per-wave staging of the gathered input rows (G, f, J of 64 cells) / the output rows
+  static constexpr int FB = ((8 * ND) % 16 == 0) ? 16 : 4; // f-row piece (LDS-DMA: 16 or 4 bytes)
+  static constexpr int NCF = 8 * ND / FB;
+  static constexpr int STG_G = 64 * ND * 2, STG_F = 64 * ND, STG_J = 64 * 4;
+  static constexpr int STG_IN = STG_G + STG_F + STG_J, STG_OUT = 64 * NRT;
+  static constexpr int STG = (STG_IN > STG_OUT) ? STG_IN : STG_OUT;
   static constexpr int lds_doubles(int block, int solver)
   {
-    return NTAB + ((K > 1 && solver == 0) ? (block / P) * LDS_GROUP : 0);
+    return NTAB + (block / 64) * STG + ((K > 1 && solver == 0) ? (block / P) * LDS_GROUP : 0);
   }
   static constexpr int block_of(int solver)
   {
@@ -130,22 +145,20 @@ struct Sizes
   }
 };
 
-template <int K, int DEG, int P, int SOLVER, int SCATTER>
-__global__ void __launch_bounds__((Sizes<K, DEG, P>::block_of(SOLVER)))
-    k_se_patch(const SeArgs a)
+template <int K, int DEG, int P, int SOLVER, int SCATTER, int BLOCK>
+__device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t block_id, double* lds)
 {
   using Z = Sizes<K, DEG, P>;
   constexpr int KB = Z::KB, NADD = Z::NADD, NDIV = Z::NDIV, NRT = Z::NRT, ND = Z::ND, NQ = Z::NQ;
   constexpr int NCOL = Z::NCOL, NH = Z::NH, NTE = Z::NTE;
-  constexpr int BLOCK = Z::block_of(SOLVER);
 
-  extern __shared__ double lds[];
   double* sF = lds;             // [3][3][ND][K]
   double* sH = sF + Z::NF;      // [3][ND][NQ]
   double* sD = sH + Z::NHT;     // [3][ND][2][NQ]
   double* sTE = sD + Z::NDT;    // [18][3][NTE]
   double* sWQ = sTE + Z::NTET;  // [18][3][NH][NCOL]
-  double* sA = sWQ + Z::NWQT;   // SOLVER 0: per-group tiles
+  double* sStage = sWQ + Z::NWQT;                 // per-wave row staging
+  double* sA = sStage + (BLOCK / 64) * Z::STG;    // SOLVER 0: per-group tiles
   (void)sA;
 
   const int tid = threadIdx.x;
@@ -156,7 +169,7 @@ __global__ void __launch_bounds__((Sizes<K, DEG, P>::block_of(SOLVER)))
   const int lane = tid & 63;
   const int sub = lane % P;          // lane within the patch group == cell index i
   const int gbase = lane - sub;      // first lane of the group within the wave
-  const int64_t patch_local = ((int64_t)blockIdx.x * BLOCK + tid) / P;
+  const int64_t patch_local = (block_id * BLOCK + tid) / P;
   const bool pvalid = patch_local < a.npatch;
   const int64_t slot = a.slot_offset + patch_local * P + sub;
   const int64_t patch = a.patch_offset + patch_local;
@@ -170,11 +183,62 @@ __global__ void __launch_bounds__((Sizes<K, DEG, P>::block_of(SOLVER)))
   const bool rev_m = (info & INFO_REV_M) != 0, rev_p = (info & INFO_REV_P) != 0;
   const int ci = (fm * 3 + fp) * 2 + (rev_m ? 1 : 0); // row of the reduced tensors
 
+  // ---- cooperative gather of this wave's input rows into LDS (LDS-DMA) ----
+  // A per-lane row load touches 64 different cache lines per wave instruction; here consecutive
+  // lanes fetch consecutive 16-byte chunks of a row, so an instruction covers 64/CH whole rows.
+  const int r = a.rhs; // one right-hand side per launch
+  double* stg = sStage + (tid >> 6) * Z::STG;
+  double* stgG = stg;
+  double* stgF = stg + Z::STG_G;
+  double* stgJ = stgF + Z::STG_F;
+  if constexpr (EQLB_STAGE_IN)
+  {
+    using gptr = const __attribute__((address_space(1))) void*;
+    using lptr = __attribute__((address_space(3))) void*;
+    const int wl0 = lane & ~63; // == 0: lane ids within the wave are 0..63
+    (void)wl0;
+    // G rows: ND chunks of 16 B (one DG node each)
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+    {
+      const int idx = i * 64 + lane, rr = idx / ND, cc = idx - rr * ND;
+      const int32_t cell_r = __shfl(cell, rr, 64);
+      const double* src = a.flux_dg + (((int64_t)r * a.ncells + cell_r) * ND + cc) * 2;
+      __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(stgG + i * 128), 16, 0, 0);
+    }
+    // f rows: 8 ND bytes in chunks of 16 / 12 / 4 bytes
+    constexpr int FB = Z::FB, NCF = Z::NCF;
+#pragma unroll
+    for (int i = 0; i < NCF; ++i)
+    {
+      const int idx = i * 64 + lane, rr = idx / NCF, cc = idx - rr * NCF;
+      const int32_t cell_r = __shfl(cell, rr, 64);
+      const char* src = reinterpret_cast<const char*>(a.rhs_dg + ((int64_t)r * a.ncells + cell_r) * ND) + cc * FB;
+      if constexpr (FB == 16)
+        __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(reinterpret_cast<char*>(stgF) + i * 64 * 16), 16, 0, 0);
+      else if constexpr (FB == 12)
+        __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(reinterpret_cast<char*>(stgF) + i * 64 * 12), 12, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(reinterpret_cast<char*>(stgF) + i * 64 * 4), 4, 0, 0);
+    }
+    // J rows: 2 chunks of 16 B
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+    {
+      const int idx = i * 64 + lane, rr = idx >> 1, cc = idx & 1;
+      const int32_t cell_r = __shfl(cell, rr, 64);
+      const double* src = a.cellJ + 4 * (int64_t)cell_r + 2 * cc;
+      __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(stgJ + i * 128), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+
   // ---- geometry (cached affine map) ----
   double J00 = 1.0, J01 = 0.0, J10 = 0.0, J11 = 1.0;
   if (active)
   {
-    const double2* Jp = reinterpret_cast<const double2*>(a.cellJ + 4 * (int64_t)cell);
+    const double2* Jp = EQLB_STAGE_IN ? reinterpret_cast<const double2*>(stgJ + 4 * lane)
+                                      : reinterpret_cast<const double2*>(a.cellJ + 4 * (int64_t)cell);
     const double2 j0 = Jp[0], j1 = Jp[1];
     J00 = j0.x;
     J01 = j0.y;
@@ -203,7 +267,6 @@ __global__ void __launch_bounds__((Sizes<K, DEG, P>::block_of(SOLVER)))
 
   // one right-hand side per launch (a.rhs): a loop over the RHS here makes the compiler hoist the
   // ~70 loop-invariant table loads of phase C above the loop and hold them in ~140 VGPRs
-  const int r = a.rhs;
   {
     const uint8_t flag = pvalid ? a.pflag[(int64_t)r * a.npatch_total + patch] : (uint8_t)0;
     const bool bc0 = (flag & PFLAG_BC0) != 0, bcn = (flag & PFLAG_BCN) != 0;
@@ -228,8 +291,10 @@ __global__ void __launch_bounds__((Sizes<K, DEG, P>::block_of(SOLVER)))
         Rq[q] = 0.0;
       if (active)
       {
-        const double2* gp_ = reinterpret_cast<const double2*>(a.flux_dg + ((int64_t)r * a.ncells + cell) * (ND * 2));
-        const double* fp_ = a.rhs_dg + ((int64_t)r * a.ncells + cell) * ND;
+        const double2* gp_ = EQLB_STAGE_IN
+                                 ? reinterpret_cast<const double2*>(stgG + lane * (ND * 2))
+                                 : reinterpret_cast<const double2*>(a.flux_dg + ((int64_t)r * a.ncells + cell) * (ND * 2));
+        const double* fp_ = EQLB_STAGE_IN ? stgF + lane * ND : a.rhs_dg + ((int64_t)r * a.ncells + cell) * ND;
         const double* tF_m = sF + (fm * 3 + ln) * ND * K;
         const double* tF_p = sF + (fp * 3 + ln) * ND * K;
         const double* tH = sH + ln * ND * NQ;
@@ -952,7 +1017,8 @@ __global__ void __launch_bounds__((Sizes<K, DEG, P>::block_of(SOLVER)))
 
       if constexpr (SCATTER == 0)
       {
-        double* o = a.out + (((int64_t)r * a.ncells + cell) * 3 + ln) * NRT;
+        // stage the row; the wave stores all rows cooperatively below (or store it directly)
+        double* o = EQLB_STAGE_OUT ? stg + lane * NRT : a.out + (((int64_t)r * a.ncells + cell) * 3 + ln) * NRT;
 #pragma unroll
         for (int e = 0; e < NRT; ++e)
           o[e] = cout[e];
@@ -965,10 +1031,89 @@ __global__ void __launch_bounds__((Sizes<K, DEG, P>::block_of(SOLVER)))
           unsafeAtomicAdd(o + e, cout[e]);
       }
     }
+    if constexpr (SCATTER == 0 && EQLB_STAGE_OUT)
+    {
+      // cooperative store of the 64 slot rows: consecutive lanes write consecutive pieces of a row
+      const int64_t key = active ? ((int64_t)r * a.ncells + cell) * 3 + ln : (int64_t)-1;
+      const int key_lo = (int)(key & 0xffffffff), key_hi = (int)(key >> 32);
+      if constexpr (NRT % 2 == 0)
+      {
+        constexpr int CH = NRT / 2; // 16-byte pieces per row
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+        {
+          const int idx = i * 64 + lane, rr = idx / CH, cc = idx - rr * CH;
+          const int64_t kr = ((int64_t)__shfl(key_hi, rr, 64) << 32) | (uint32_t)__shfl(key_lo, rr, 64);
+          const double2 v = reinterpret_cast<const double2*>(stg)[idx];
+          if (kr >= 0)
+            reinterpret_cast<double2*>(a.out + kr * NRT)[cc] = v;
+        }
+      }
+      else
+      {
+#pragma unroll
+        for (int i = 0; i < NRT; ++i)
+        {
+          const int idx = i * 64 + lane, rr = idx / NRT, cc = idx - rr * NRT;
+          const int64_t kr = ((int64_t)__shfl(key_hi, rr, 64) << 32) | (uint32_t)__shfl(key_lo, rr, 64);
+          const double v = stg[idx];
+          if (kr >= 0)
+            a.out[kr * NRT + cc] = v;
+        }
+      }
+    }
   }
 
   if (status_local)
     atomicOr(a.status, 1);
+}
+
+// one bin per launch (any solver)
+template <int K, int DEG, int P, int SOLVER, int SCATTER>
+__global__ void __launch_bounds__((Sizes<K, DEG, P>::block_of(SOLVER))) k_se_patch(const SeArgs a)
+{
+  extern __shared__ double lds[];
+  se_patch_body<K, DEG, P, SOLVER, SCATTER, Sizes<K, DEG, P>::block_of(SOLVER)>(a, blockIdx.x, lds);
+}
+
+// all bins in ONE launch (register solver): blocks [start[b], start[b+1]) run the P = 4 << b body,
+// so the bins overlap on the chip and there are no launch gaps / tails between them
+template <int K, int DEG, int SOLVER, int SCATTER>
+#ifndef EQLB_FUSED_WAVES
+#define EQLB_FUSED_WAVES 4
+#endif
+__global__ void __launch_bounds__(256, (K <= 2 ? EQLB_FUSED_WAVES : 1)) k_se_patch_fused(const SeArgs a0, const FusedBins fb)
+{
+  extern __shared__ double lds[];
+  const int64_t bid = blockIdx.x;
+  int b = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_BINS; ++i)
+    if (bid >= fb.block_start[i])
+      b = i;
+  SeArgs a = a0;
+  a.npatch = fb.npatch[b];
+  a.slot_offset = fb.slot_offset[b];
+  a.patch_offset = fb.patch_offset[b];
+  const int64_t lb = bid - fb.block_start[b];
+  switch (b)
+  {
+  case 0:
+    se_patch_body<K, DEG, 4, SOLVER, SCATTER, 256>(a, lb, lds);
+    break;
+  case 1:
+    se_patch_body<K, DEG, 8, SOLVER, SCATTER, 256>(a, lb, lds);
+    break;
+  case 2:
+    se_patch_body<K, DEG, 16, SOLVER, SCATTER, 256>(a, lb, lds);
+    break;
+  case 3:
+    se_patch_body<K, DEG, 32, SOLVER, SCATTER, 256>(a, lb, lds);
+    break;
+  default:
+    se_patch_body<K, DEG, 64, SOLVER, SCATTER, 256>(a, lb, lds);
+    break;
+  }
 }
 
 // flux_hdiv[r][cell][i] += slot0 + slot1 + slot2  (fixed order -> bitwise reproducible)
@@ -1057,6 +1202,32 @@ static int launch_kd(int P, int solver, int scatter, const SeArgs& a, hipStream_
   if (scatter == EQLB_SCATTER_SLOTS)
     return launch_p<K, DEG, 0, 0>(P, a, stream);
   return launch_p<K, DEG, 0, 1>(P, a, stream);
+}
+
+template <int K, int DEG>
+static int launch_fused_kd(int scatter, const SeArgs& a, const FusedBins& fb, hipStream_t stream)
+{
+  const size_t lds_bytes = sizeof(double) * (size_t)Sizes<K, DEG, 8>::lds_doubles(256, 1);
+  const int64_t grid = fb.block_start[MAX_BINS];
+  if (grid == 0)
+    return 0;
+  if (scatter == EQLB_SCATTER_SLOTS)
+    hipLaunchKernelGGL((k_se_patch_fused<K, DEG, 1, 0>), dim3((unsigned)grid), dim3(256), lds_bytes, stream, a, fb);
+  else
+    hipLaunchKernelGGL((k_se_patch_fused<K, DEG, 1, 1>), dim3((unsigned)grid), dim3(256), lds_bytes, stream, a, fb);
+  return (hipGetLastError() == hipSuccess) ? 0 : EQLB_ERR_DEVICE;
+}
+
+int launch_se_patch_fused(int k, int deg, int scatter, const SeArgs& a, const FusedBins& fb,
+                          hipStream_t stream)
+{
+  if (k == 1 && deg == 0)
+    return launch_fused_kd<1, 0>(scatter, a, fb, stream);
+  if (k == 2 && deg == 1)
+    return launch_fused_kd<2, 1>(scatter, a, fb, stream);
+  if (k == 3 && deg == 2)
+    return launch_fused_kd<3, 2>(scatter, a, fb, stream);
+  return EQLB_ERR_UNSUPPORTED;
 }
 
 int launch_se_patch(int k, int deg, int P, int solver, int scatter, const SeArgs& a,

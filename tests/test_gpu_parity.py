@@ -22,11 +22,12 @@ def cpp():
     return c
 
 
-def _gpu(cpp, mesh, k, ft, G, f, scatter=0, solver=0, node_mask=None, x0=None):
+def _gpu(cpp, mesh, k, ft, G, f, scatter=0, solver=1, node_mask=None, x0=None, fused=1):
     dm = cpp.DeviceMesh(mesh)
     eq = cpp.SemiExplicitEquilibrator(dm, k, G.shape[0])
     eq.set_option("scatter", scatter)
     eq.set_option("solver", solver)
+    eq.set_option("fused", fused)
     eq.set_boundary(ft, node_mask=node_mask)
     return eq.equilibrate_host(G, f, x0), eq
 
@@ -92,6 +93,14 @@ def test_multirhs_with_different_bcs(cpp, oracle_mod, k):
         x, _ = _gpu(cpp, mesh, k, ft, G, f, solver=solver)
         ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f)
         assert np.abs(x - ref).max() <= RTOL * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_fused_launch_equals_per_bin_launches(cpp, k):
+    mesh, ft, G, f = make_case(9, k, "neumann_lt")
+    a, _ = _gpu(cpp, mesh, k, ft, G, f, fused=1)
+    b, _ = _gpu(cpp, mesh, k, ft, G, f, fused=0)
+    assert np.array_equal(a, b)
 
 
 def test_accumulates_and_is_reproducible(cpp):
