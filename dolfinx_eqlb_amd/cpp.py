@@ -24,6 +24,7 @@ EXPORTED_SYMBOLS = [
     "eqlb_mesh_max_patch_cells", "eqlb_se_create", "eqlb_se_destroy", "eqlb_se_set_option",
     "eqlb_se_set_boundary", "eqlb_se_equilibrate", "eqlb_se_num_patches",
     "eqlb_se_export_patches", "eqlb_get_reference_table", "eqlb_se_last_kernel_ms",
+    "eqlb_project_dg",
 ]
 
 _lib = None
@@ -186,6 +187,24 @@ class SemiExplicitEquilibrator:
             self.close()
         except Exception:
             pass
+
+
+def project_dg(dmesh: DeviceMesh, degree: int, qpoints, qweights, qvalues, bs: int = 1):
+    """eqlb_project_dg on host arrays: qvalues [nrhs, ncells, nq, bs] -> DOFs [nrhs, ncells*nd*bs]."""
+    m = dmesh.mesh
+    qp = np.ascontiguousarray(qpoints, dtype=np.float64)
+    qw = np.ascontiguousarray(qweights, dtype=np.float64)
+    nq = qw.size
+    qv = np.ascontiguousarray(qvalues, dtype=np.float64)
+    if qv.size % (m.ncells * nq * bs) != 0:
+        raise RuntimeError("Local solver: Input sizes does not match")
+    nrhs = qv.size // (m.ncells * nq * bs)
+    nd = (degree + 1) * (degree + 2) // 2
+    out = np.zeros((nrhs, m.ncells * nd * bs))
+    _check(lib().eqlb_project_dg(dmesh._h, C.c_int32(degree), C.c_int32(bs), C.c_int32(nrhs),
+                                 C.c_int32(nq), _hp(qp), _hp(qw), _hp(qv), _hp(out),
+                                 C.c_int32(MEM_HOST), None))
+    return out
 
 
 def get_reference_table(k, degree_dg, name):

@@ -596,6 +596,54 @@ double eqlb_se_last_kernel_ms(const eqlb_se_t* h, int32_t which)
   return sum / (double)nset;
 }
 
+int eqlb_project_dg(eqlb_mesh_t* mesh, int32_t degree, int32_t bs, int32_t nrhs, int32_t nq,
+                    const double* qpoints, const double* qweights, const double* qvalues,
+                    double* out, int32_t memspace, void* stream_)
+{
+  if (!mesh || !qpoints || !qweights || !qvalues || !out || bs < 1 || nrhs < 1)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "Local solver: Input sizes does not match");
+  std::vector<double> Pm;
+  const int st = eqlb::projection_matrix_host(degree, nq, qpoints, qweights, Pm);
+  if (st)
+    return fail(st, "eqlb_project_dg: unsupported degree %d or number of points %d", degree, nq);
+  const int nd = (degree + 1) * (degree + 2) / 2;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int64_t ncells = (int64_t)mesh->m.ncells * nrhs; // the RHS are stacked cell blocks
+  const size_t n_in = (size_t)ncells * nq * bs, n_out = (size_t)ncells * nd * bs;
+  double *d_P = nullptr, *d_in = nullptr, *d_out = nullptr;
+  if (upload(&d_P, Pm.data(), Pm.size()))
+    return EQLB_ERR_DEVICE;
+  int rc = EQLB_OK;
+  if (memspace == EQLB_MEM_HOST)
+  {
+    if (upload(&d_in, qvalues, n_in) || upload<double>(&d_out, nullptr, n_out))
+      rc = EQLB_ERR_DEVICE;
+  }
+  else
+  {
+    d_in = const_cast<double*>(qvalues);
+    d_out = out;
+  }
+  if (!rc)
+  {
+    eqlb::launch_project_dg(ncells, nd, nq, bs, d_P, d_in, d_out, stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && memspace == EQLB_MEM_HOST)
+      e = hipMemcpy(out, d_out, n_out * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(stream); // d_P is freed below
+    if (e != hipSuccess)
+      rc = fail(EQLB_ERR_DEVICE, "eqlb_project_dg: %s", hipGetErrorString(e));
+  }
+  dfree(d_P);
+  if (memspace == EQLB_MEM_HOST)
+  {
+    dfree(d_in);
+    dfree(d_out);
+  }
+  return rc;
+}
+
 int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, double* out,
                              int32_t capacity)
 {

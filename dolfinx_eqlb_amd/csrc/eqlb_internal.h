@@ -103,6 +103,10 @@ int launch_se_patch_fused(int k, int deg, int scatter, const SeArgs& a, const Fu
                           hipStream_t stream);
 void launch_reduce_slots(int nrt, int32_t ncells, int32_t nrhs, const double* slots, double* x,
                          hipStream_t stream);
+int projection_matrix_host(int degree, int nq, const double* pts, const double* wts,
+                           std::vector<double>& Pm);
+void launch_project_dg(int64_t ncells, int nd, int nq, int bs, const double* Pm, const double* qv,
+                       double* out, hipStream_t stream);
 size_t table_doubles(int k, int deg);
 int fill_tables_host(int k, int deg, std::vector<double>& out);
 

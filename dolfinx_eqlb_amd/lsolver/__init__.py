@@ -1,0 +1,5 @@
+"""Cell-local solvers: mirror of python/dolfinx_eqlb/lsolver (projection.py, lsolver.py)."""
+
+from .projection import local_projection
+
+__all__ = ["local_projection"]

@@ -1,0 +1,43 @@
+"""Cell-local L2 projection into DG spaces on the GPU - mirror of
+python/dolfinx_eqlb/lsolver/projection.py:17-77 (`local_projection`) on flat arrays.
+
+The reference takes UFL expressions and JIT-compiles the load kernels; here the data are Python
+callables f(x, y) -> array [..., bs] (or [...] for bs = 1) evaluated at the physical quadrature
+points, or precomputed point values.
+"""
+
+import typing
+
+import numpy as np
+
+from .. import cpp
+from ..elmtlib.quadrature import make_quadrature_triangle
+from ..eqlb.check_eqlb_conditions import cell_geometry
+
+
+def quadrature_points_physical(mesh, qpoints):
+    """x_c(X_q) for all cells: [ncells, nq, 2]."""
+    J, _, _ = cell_geometry(mesh)
+    x0 = mesh.x[mesh.cell_nodes[:, 0], :2]
+    return x0[:, None, :] + np.einsum("cij,qj->cqi", J, qpoints)
+
+
+def local_projection(dmesh: "cpp.DeviceMesh", degree: int, data: typing.List[typing.Any], bs: int = 1,
+                     quadrature_degree: typing.Optional[int] = None) -> typing.List[np.ndarray]:
+    """Project every entry of `data` into DG_degree (block size bs); returns the DOF arrays
+    [ncells*nd*bs] (cell-major, x[bs*dof+cb]).  data[i]: callable(x, y) or array [ncells, nq, bs]."""
+    mesh = dmesh.mesh
+    qdeg = 2 * degree + 2 if quadrature_degree is None else quadrature_degree
+    qp, qw = make_quadrature_triangle(qdeg)
+    xq = None
+    vals = []
+    for d in data:
+        if callable(d):
+            if xq is None:
+                xq = quadrature_points_physical(mesh, qp)
+            v = np.asarray(d(xq[..., 0], xq[..., 1]), dtype=np.float64)
+        else:
+            v = np.asarray(d, dtype=np.float64)
+        vals.append(v.reshape(mesh.ncells, qw.size, bs))
+    out = cpp.project_dg(dmesh, degree, qp, qw, np.stack(vals), bs)
+    return [out[i] for i in range(len(data))]

@@ -150,6 +150,23 @@ int eqlb_se_export_patches(eqlb_se_t* handle, int32_t stride, int32_t* ncells, i
                            int32_t* fcts, int8_t* fcts_local, int8_t* inodes_local,
                            int8_t* reversed);
 
+/*
+ * Cell-local L2 projection into DG_degree (scalar: bs = 1, blocked vector: bs = 2, ...), the loop of
+ * base::local_solver_cholesky (cpp/dolfinx_eqlb/base/local_solver.hpp:38-187,214-224) as used by
+ * local_projection (python/dolfinx_eqlb/lsolver/projection.py:17-77; forms a = (u,v), l_i = (f_i,v)).
+ * The reference evaluates f_i inside JIT-compiled FFCx kernels; here the caller supplies its point
+ * values at the images of a reference-cell quadrature rule of its choice (exact for
+ * deg(f) + degree on affine cells):
+ *   qpoints [nq][2], qweights [nq]   rule on the reference triangle (weights sum to 1/2), host
+ *   qvalues [nrhs][ncells][nq][bs]   f_i at x_c(qpoints)
+ *   out     [nrhs][ncells][nd][bs]   DOFs (= x[bs*dof + cb], cell-major DG numbering); OVERWRITTEN
+ *                                    like the reference (:163-182), nd = (degree+1)(degree+2)/2
+ * degree <= 3, nq <= 64.  memspace / stream as in eqlb_se_equilibrate (qvalues and out).
+ */
+int eqlb_project_dg(eqlb_mesh_t* mesh, int32_t degree, int32_t bs, int32_t nrhs, int32_t nq,
+                    const double* qpoints, const double* qweights, const double* qvalues,
+                    double* out, int32_t memspace, void* stream);
+
 /* Largest number of cells of a patch of the mesh (OrientedPatch::ncells_max). */
 int32_t eqlb_mesh_max_patch_cells(const eqlb_mesh_t* mesh);
 

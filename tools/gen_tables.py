@@ -183,6 +183,23 @@ def emit(path):
         arr("WQ", (18, 3, nh_, 2 * k + ndiv_), t["WQ"])
         lines.append("};")
         lines.append("")
+    # Lagrange P_d (Basix numbering, equispaced): monomial coefficients and inverse mass matrix
+    lines.append("// Lagrange P_d on the reference triangle: LAG_COEF[i][m] = coefficient of monomial m")
+    lines.append("// (order: deg 0; x, y; x^2, xy, y^2; ...) of basis function i; LAG_MINV = inverse of int psi_i psi_j")
+    lines.append("template <int DEG> struct Lag;")
+    for deg in range(4):
+        dg = Lagrange(deg)
+        nd = dg.ndofs
+        monos = [(a, d - a) for d in range(deg + 1) for a in range(d, -1, -1)]
+        coef = [[dg.basis[i].get(m, Fraction(0)) for m in monos] for i in range(nd)]
+        mass = [[P.integrate_triangle(P.mul(dg.basis[i], dg.basis[j])) for j in range(nd)] for i in range(nd)]
+        minv = P.solve_exact(mass, [[Fraction(int(i == j)) for j in range(nd)] for i in range(nd)])
+        lines.append(f"template <> struct Lag<{deg}> {{")
+        lines.append(f"  static constexpr int ND = {nd};")
+        lines.append(f"  static constexpr double COEF[{nd * nd}] = {{" + ", ".join(repr(float(v)) for v in _flat(coef)) + "};")
+        lines.append(f"  static constexpr double MINV[{nd * nd}] = {{" + ", ".join(repr(float(v)) for v in _flat(minv)) + "};")
+        lines.append("};")
+    lines.append("")
     lines.append("// reference facet normals of the RT functionals (e_raviart_thomas.py:82) and whether the")
     lines.append("// functional measures the outward flux")
     lines.append("static constexpr double NREF[3][2] = {{-1.0, -1.0}, {-1.0, 0.0}, {0.0, 1.0}};")
