@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "eqlb_mesh_max_patch_cells", "eqlb_se_create", "eqlb_se_destroy", "eqlb_se_set_option",
     "eqlb_se_set_boundary", "eqlb_se_equilibrate", "eqlb_se_num_patches",
     "eqlb_se_export_patches", "eqlb_get_reference_table", "eqlb_se_last_kernel_ms",
-    "eqlb_project_dg",
+    "eqlb_project_dg", "eqlb_se_equilibrate_with_kornconst",
 ]
 
 _lib = None
@@ -150,6 +150,21 @@ class SemiExplicitEquilibrator:
         _check(lib().eqlb_se_equilibrate(self._h, _hp(g), _hp(f), _hp(flux_hdiv),
                                          C.c_int32(MEM_HOST), None))
         return flux_hdiv
+
+    def equilibrate_host_with_kornconst(self, flux_dg, rhs_dg, flux_hdiv=None, korn=None):
+        """As equilibrate_host, plus the accumulated squared Korn constants [ncells]."""
+        m = self.dmesh.mesh
+        g = np.ascontiguousarray(flux_dg, dtype=np.float64).reshape(self.nrhs, -1)
+        f = np.ascontiguousarray(rhs_dg, dtype=np.float64).reshape(self.nrhs, -1)
+        if g.shape[1] != m.ncells * self.nd * 2 or f.shape[1] != m.ncells * self.nd:
+            raise RuntimeError("Equilibration: Input sizes does not match")
+        if flux_hdiv is None:
+            flux_hdiv = np.zeros((self.nrhs, m.ncells * self.nrt))
+        if korn is None:
+            korn = np.zeros(m.ncells)
+        _check(lib().eqlb_se_equilibrate_with_kornconst(self._h, _hp(g), _hp(f), _hp(flux_hdiv),
+                                                        _hp(korn), C.c_int32(MEM_HOST), None))
+        return flux_hdiv, korn
 
     def equilibrate_device(self, flux_dg_ptr: int, rhs_dg_ptr: int, flux_hdiv_ptr: int,
                            stream: int = 0):

@@ -174,8 +174,7 @@ int eqlb_se_create(eqlb_mesh_t* mesh, int32_t k, int32_t degree_dg, int32_t nrhs
       return fail(EQLB_ERR_INVALID_ARGUMENT, "Stress equilibration: RT_k with k>1 required!");
     return fail(EQLB_ERR_UNSUPPORTED, "stress equilibration (weak symmetry) is not in this build");
   }
-  if (estimate_korn)
-    return fail(EQLB_ERR_UNSUPPORTED, "Korn constant estimation is not in this build");
+  (void)estimate_korn;
   std::vector<double> tab;
   if (eqlb::fill_tables_host(k, degree_dg, tab) != 0 || degree_dg != k - 1 || k > 3)
     return fail(EQLB_ERR_UNSUPPORTED, "RT_%d with DG_%d data is not in this build", k, degree_dg);
@@ -209,6 +208,8 @@ void eqlb_se_destroy(eqlb_se_t* h)
   dfree(h->d_flux_dg);
   dfree(h->d_rhs_dg);
   dfree(h->d_flux_hdiv);
+  dfree(h->d_cks);
+  dfree(h->d_korn);
   if (h->ev)
   {
     for (int i = 0; i < eqlb_se::EV_RING * eqlb_se::EV_PER_SET; ++i)
@@ -352,6 +353,38 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   h->boundary_set = true;
+  return EQLB_OK;
+}
+
+int eqlb_se_equilibrate_with_kornconst(eqlb_se_t* h, const double* flux_dg, const double* rhs_dg,
+                                       double* flux_hdiv, double* cells_kornconst,
+                                       int32_t memspace, void* stream_)
+{
+  if (!cells_kornconst)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "Equilibration: Input sizes does not match");
+  const int st = eqlb_se_equilibrate(h, flux_dg, rhs_dg, flux_hdiv, memspace, stream_);
+  if (st)
+    return st;
+  const eqlb::DeviceMesh& m = h->mesh->m;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!h->d_cks && upload<double>(&h->d_cks, nullptr, (size_t)m.nnodes))
+    return EQLB_ERR_DEVICE;
+  double* d_korn = cells_kornconst;
+  if (memspace == EQLB_MEM_HOST)
+  {
+    if (!h->d_korn && upload<double>(&h->d_korn, nullptr, (size_t)m.ncells))
+      return EQLB_ERR_DEVICE;
+    HIP_TRY(hipMemcpyAsync(h->d_korn, cells_kornconst, sizeof(double) * m.ncells, hipMemcpyHostToDevice, stream));
+    d_korn = h->d_korn;
+  }
+  eqlb::launch_korn(m, h->node_slot, h->node_patch, h->slot_cell, h->slot_info, h->pn, h->pflag,
+                    h->d_cks, d_korn, stream);
+  HIP_TRY(hipGetLastError());
+  if (memspace == EQLB_MEM_HOST)
+  {
+    HIP_TRY(hipMemcpyAsync(cells_kornconst, d_korn, sizeof(double) * m.ncells, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+  }
   return EQLB_OK;
 }
 

@@ -107,6 +107,9 @@ int projection_matrix_host(int degree, int nq, const double* pts, const double* 
                            std::vector<double>& Pm);
 void launch_project_dg(int64_t ncells, int nd, int nq, int bs, const double* Pm, const double* qv,
                        double* out, hipStream_t stream);
+void launch_korn(const DeviceMesh& m, const int64_t* node_slot, const int64_t* node_patch,
+                 const int32_t* slot_cell, const uint32_t* slot_info, const uint8_t* pn,
+                 const uint8_t* pflag, double* cks, double* korn, hipStream_t stream);
 size_t table_doubles(int k, int deg);
 int fill_tables_host(int k, int deg, std::vector<double>& out);
 
@@ -140,6 +143,7 @@ struct eqlb_se
   int32_t* status = nullptr;
   // staging for host-memory calls
   double *d_flux_dg = nullptr, *d_rhs_dg = nullptr, *d_flux_hdiv = nullptr;
+  double *d_cks = nullptr, *d_korn = nullptr; // Korn estimate: per node / staging per cell
   // timing ("timing" option): ring of event sets, one set per equilibrate call
   static constexpr int EV_RING = 64, EV_PER_SET = 2 * eqlb::MAX_BINS + 2;
   hipEvent_t* ev = nullptr; // [EV_RING][EV_PER_SET]: bin b start/end at 2b, 2b+1; reduce start/end

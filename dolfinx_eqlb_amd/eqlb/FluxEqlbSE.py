@@ -54,6 +54,8 @@ class FluxEqlbSE:
                                                 estimate_korn_constant)
         ndofs = degree_flux * (degree_flux + 2)
         self.list_flux = np.zeros((self.n_fluxes, msh.ncells * ndofs))
+        if estimate_korn_constant:
+            self.korn_constants = np.zeros(msh.ncells)  # DG0 function of the reference
         self.boundary_data = None
 
     def set_boundary_conditions(self, list_bfct_prime: typing.List[np.ndarray],
@@ -75,9 +77,16 @@ class FluxEqlbSE:
         """Equilibrate the fluxes (accumulates into list_flux like the reference)."""
         if self.boundary_data is None:
             raise RuntimeError("Boundary conditions have not been set")
-        cpp.reconstruct_fluxes_semiexplt(self.list_flux, np.stack(self.list_proj_flux),
-                                         np.stack(self.list_rhs), self.boundary_data,
-                                         self.equilibrate_stresses)
+        if self.estimate_korn_constant:
+            # reconstruct_fluxes_semiexplt_with_kornconst + sqrt (FluxEqlbSE.py:152-166)
+            self._eq.equilibrate_host_with_kornconst(np.stack(self.list_proj_flux),
+                                                     np.stack(self.list_rhs), self.list_flux,
+                                                     self.korn_constants)
+            self.korn_constants[:] = np.sqrt(self.korn_constants)
+        else:
+            cpp.reconstruct_fluxes_semiexplt(self.list_flux, np.stack(self.list_proj_flux),
+                                             np.stack(self.list_rhs), self.boundary_data,
+                                             self.equilibrate_stresses)
 
     def get_reconstructed_fluxes(self, subproblem: int):
         """(corrector in discontinuous hierarchic RT_k, projected flux in DG_{k-1}^2): the
@@ -85,4 +94,6 @@ class FluxEqlbSE:
         return self.list_flux[subproblem], self.list_proj_flux[subproblem]
 
     def get_korn_constants(self):
+        if self.estimate_korn_constant:
+            return self.korn_constants
         raise RuntimeError("Korn constants are not estimated!")

@@ -88,7 +88,8 @@ void eqlb_mesh_destroy(eqlb_mesh_t* mesh);
  * KernelData tabulation, kernel generation, Patch/PatchData allocation) - done once here and
  * cached on the device.  reconstruct_stress / korn are the flags of
  * reconstruct_fluxes_semiexplt[_with_kornconst] (wrappers.cpp:97-137); stress equilibration
- * is not in this build (EQLB_ERR_UNSUPPORTED).
+ * is not in this build (EQLB_ERR_UNSUPPORTED); estimate_korn is accepted for symmetry with the
+ * reference constructor (the estimate itself is requested per call, see below).
  */
 int eqlb_se_create(eqlb_mesh_t* mesh, int32_t k, int32_t degree_dg, int32_t nrhs,
                    int32_t reconstruct_stress, int32_t estimate_korn, eqlb_se_t** handle);
@@ -134,6 +135,17 @@ int eqlb_se_set_boundary(eqlb_se_t* handle, const int8_t* facet_type,
  */
 int eqlb_se_equilibrate(eqlb_se_t* handle, const double* flux_dg, const double* rhs_dg,
                         double* flux_hdiv, int32_t memspace, void* stream);
+
+/*
+ * Same as eqlb_se_equilibrate plus the upper bounds of the cells' squared Korn constants:
+ * reconstruct_fluxes_semiexplt_with_kornconst (wrappers.cpp:117-137) =
+ * se/reconstruction.hpp:291-304 with OrientedPatch::estimate_squared_korn_constant
+ * (se/Patch.cpp:130-334).  cells_kornconst [ncells] is ACCUMULATED: every patch adds
+ * (gdim+1) c_K^2 to its cells; the Python caller takes the square root (FluxEqlbSE.py:165).
+ */
+int eqlb_se_equilibrate_with_kornconst(eqlb_se_t* handle, const double* flux_dg,
+                                       const double* rhs_dg, double* flux_hdiv,
+                                       double* cells_kornconst, int32_t memspace, void* stream);
 
 /* Number of patches equilibrated per call (nodes selected by node_mask). */
 int64_t eqlb_se_num_patches(const eqlb_se_t* handle);

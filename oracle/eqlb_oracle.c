@@ -8,7 +8,11 @@
  */
 #include "eqlb_oracle.h"
 
+#define _USE_MATH_DEFINES
 #include <math.h>
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
 #include <stdlib.h>
 #include <string.h>
 
@@ -1178,6 +1182,147 @@ static int equilibrate_patch(patch_t* p, pdata_t* d, const oracle_tables_t* tab,
     }
   }
   return status;
+}
+
+/* OrientedPatch::estimate_squared_korn_constant, se/Patch.cpp:130-334 (Kim's bound
+ * 2 / sin^2(theta_min / 2) for star-shaped patches) */
+static double estimate_squared_korn_constant(const patch_t* p)
+{
+  const oracle_mesh_t* m = p->m;
+  const double* x = m->x;
+  const int node_patch = p->node;
+  const int n = p->ncells, nf = p->nfcts;
+  double theta_min;
+  if (p->type[0] == PT_INTERNAL)
+  {
+    const double xi0 = x[3 * (size_t)node_patch], xi1 = x[3 * (size_t)node_patch + 1];
+    theta_min = 0.5 * M_PI;
+    /* cells() of an interior patch = _cells[0 .. n+1] (se/Patch.hpp:222-232): T_n, T_1..T_n, T_1 */
+    for (int a = 0; a < n + 2; ++a)
+    {
+      const int32_t cell = p->cells[a];
+      const int32_t* cn = m->cell_nodes + 3 * (size_t)cell;
+      int32_t b[2];
+      int cnt = 0;
+      for (int j = 0; j < 3; ++j)
+        if (cn[j] != node_patch)
+          b[cnt++] = 3 * cn[j];
+      double v2[2] = {x[b[1]] - x[b[0]], x[b[1] + 1] - x[b[0] + 1]};
+      const double abs_v2 = sqrt(v2[0] * v2[0] + v2[1] * v2[1]);
+      double v1[2] = {xi0 - x[b[0]], xi1 - x[b[0] + 1]};
+      double abs_v1 = sqrt(v1[0] * v1[0] + v1[1] * v1[1]);
+      double v1_t_v2 = v1[0] * v2[0] + v1[1] * v2[1];
+      theta_min = fmin(theta_min, acos(v1_t_v2 / (abs_v1 * abs_v2)));
+      v1[0] = xi0 - x[b[1]];
+      v1[1] = xi1 - x[b[1] + 1];
+      abs_v1 = sqrt(v1[0] * v1[0] + v1[1] * v1[1]);
+      v1_t_v2 = v1[0] * v2[0] + v1[1] * v2[1];
+      theta_min = fmin(theta_min, acos(-v1_t_v2 / (abs_v1 * abs_v2)));
+    }
+  }
+  else
+  {
+    double cnodes[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    double phi_min[3] = {M_PI, M_PI, M_PI};
+    if (n % 2 == 0)
+    {
+      const int h = n / 2;
+      for (int i = 0; i < 2; ++i)
+      {
+        const int32_t* en = m->cell_nodes + 3 * (size_t)p->cells[h + i];
+        for (int j = 0; j < 3; ++j)
+        {
+          cnodes[i][0] += x[3 * (size_t)en[j]] / 3;
+          cnodes[i][1] += x[3 * (size_t)en[j] + 1] / 3;
+        }
+      }
+      const int32_t* en = m->facet_nodes + 2 * (size_t)p->fcts[h];
+      for (int j = 0; j < 2; ++j)
+      {
+        cnodes[2][0] += 0.5 * x[3 * (size_t)en[j]];
+        cnodes[2][1] += 0.5 * x[3 * (size_t)en[j] + 1];
+      }
+    }
+    else
+    {
+      const int h = nf / 2;
+      for (int i = 0; i < 2; ++i)
+      {
+        const int32_t* en = m->facet_nodes + 2 * (size_t)p->fcts[h - i];
+        for (int j = 0; j < 2; ++j)
+        {
+          cnodes[i][0] += 0.5 * x[3 * (size_t)en[j]];
+          cnodes[i][1] += 0.5 * x[3 * (size_t)en[j] + 1];
+        }
+      }
+      const int32_t* en = m->cell_nodes + 3 * (size_t)p->cells[h];
+      for (int j = 0; j < 3; ++j)
+      {
+        cnodes[2][0] += x[3 * (size_t)en[j]] / 3;
+        cnodes[2][1] += x[3 * (size_t)en[j] + 1] / 3;
+      }
+    }
+    /* walk the patch boundary starting at the patch node (:273-321) */
+    int32_t node_i = node_patch, idn_i = 3 * node_i;
+    const int32_t* en = m->facet_nodes + 2 * (size_t)p->fcts[n];
+    int32_t node_im1 = (en[0] == node_i) ? en[1] : en[0];
+    int32_t idn_im1 = 3 * node_im1;
+    double v2[2] = {x[idn_im1] - x[idn_i], x[idn_im1 + 1] - x[idn_i + 1]};
+    double abs_v2 = sqrt(v2[0] * v2[0] + v2[1] * v2[1]);
+    for (int i = 0; i < nf; ++i)
+    {
+      const int32_t* e2 = m->facet_nodes + 2 * (size_t)p->fcts[i];
+      const int32_t node_ip1 = (e2[0] == node_patch) ? e2[1] : e2[0];
+      const int32_t idn_ip1 = 3 * node_ip1;
+      double v3[2] = {x[idn_ip1] - x[idn_i], x[idn_ip1 + 1] - x[idn_i + 1]};
+      const double abs_v3 = sqrt(v3[0] * v3[0] + v3[1] * v3[1]);
+      for (int j = 0; j < 3; ++j)
+      {
+        const double v1[2] = {cnodes[j][0] - x[idn_i], cnodes[j][1] - x[idn_i + 1]};
+        const double abs_v1 = sqrt(v1[0] * v1[0] + v1[1] * v1[1]);
+        double d = v1[0] * v2[0] + v1[1] * v2[1];
+        phi_min[j] = fmin(phi_min[j], acos(d / (abs_v1 * abs_v2)));
+        d = v1[0] * v3[0] + v1[1] * v3[1];
+        phi_min[j] = fmin(phi_min[j], acos(d / (abs_v1 * abs_v3)));
+      }
+      node_i = node_ip1;
+      idn_i = idn_ip1;
+      v2[0] = -v3[0];
+      v2[1] = -v3[1];
+      abs_v2 = abs_v3;
+    }
+    theta_min = 0.0;
+    for (int j = 0; j < 3; ++j)
+      theta_min = fmax(theta_min, phi_min[j]);
+  }
+  return 2 * pow(sin(theta_min / 2), -2);
+}
+
+/* Korn part of the node loop, se/reconstruction.hpp:291-304: every patch adds
+ * (gdim + 1) * c_K^2 to all its cells; korn [ncells] is accumulated. */
+int oracle_se_korn(const oracle_mesh_t* mesh, int nrhs, const int8_t* facet_type, double* korn,
+                   int32_t node_begin, int32_t node_end)
+{
+  patch_t p;
+  pdata_t d;
+  oracle_tables_t tab;
+  memset(&tab, 0, sizeof(tab));
+  tab.k = 1;
+  tab.ndofs = 3;
+  tab.nd = 1;
+  tab.ndf = 1;
+  tab.nq = 1;
+  tab.nqf = 1;
+  patch_alloc(&p, &d, mesh, &tab, nrhs, facet_type);
+  for (int32_t node = node_begin; node < node_end; ++node)
+  {
+    initialize_patch(&p, node);
+    const double cks = estimate_squared_korn_constant(&p) * 3;
+    for (int a = 1; a <= p.ncells; ++a)
+      korn[p.cells[a]] += cks;
+  }
+  patch_free(&p, &d);
+  return 0;
 }
 
 /* ------------------------------------------------------------------------------------ */

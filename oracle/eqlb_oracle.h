@@ -91,6 +91,12 @@ int oracle_se_patch(const oracle_mesh_t* mesh, const oracle_tables_t* tab, int n
                     double* out_sigma_tilde, double* out_patch, int32_t* out_cells,
                     double* out_u);
 
+/* Squared Korn constants: node loop part of se/reconstruction.hpp:291-304 with
+ * OrientedPatch::estimate_squared_korn_constant (se/Patch.cpp:130-334); korn [ncells] accumulated
+ * (the Python caller takes the square root, FluxEqlbSE.py:165). */
+int oracle_se_korn(const oracle_mesh_t* mesh, int nrhs, const int8_t* facet_type, double* korn,
+                   int32_t node_begin, int32_t node_end);
+
 #ifdef __cplusplus
 }
 #endif

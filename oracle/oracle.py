@@ -53,6 +53,7 @@ def _load():
         _lib.oracle_se_reconstruct.restype = C.c_int
         _lib.oracle_se_patch.restype = C.c_int
         _lib.oracle_build_patches.restype = C.c_int
+        _lib.oracle_se_korn.restype = C.c_int
     return _lib
 
 
@@ -139,6 +140,20 @@ def se_patch(mesh, k, facet_type, flux_dg, rhs_dg, node, boundary_values=None, d
     if st < 0:
         raise RuntimeError(f"oracle failed with status {st}")
     return cells, st_, sol, u
+
+
+def se_korn(mesh, facet_type, node_range=None):
+    """Accumulated squared Korn constants per cell (before the square root of FluxEqlbSE.py:165)."""
+    lib = _load()
+    facet_type = np.ascontiguousarray(facet_type, dtype=np.int8).reshape(-1, mesh.nfacets)
+    ms, keep_m = _mesh_struct(mesh)
+    nb, ne = node_range if node_range is not None else (0, mesh.nnodes)
+    korn = np.zeros(mesh.ncells)
+    st = lib.oracle_se_korn(C.byref(ms), C.c_int(facet_type.shape[0]), _p(facet_type), _p(korn),
+                            C.c_int32(nb), C.c_int32(ne))
+    if st != 0:
+        raise RuntimeError(f"oracle failed with status {st}")
+    return korn
 
 
 def build_patches(mesh, facet_type, node_range=None):
