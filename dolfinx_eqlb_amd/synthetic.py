@@ -142,3 +142,87 @@ def compatibility_residual(mesh, k, facet_type, flux_dg, rhs_dg, degree_dg=None)
     fixed = np.zeros(mesh.nnodes, dtype=bool)
     fixed[mesh.facet_nodes[ft == 1].ravel()] = True
     return float(np.max(np.abs(r[~fixed]))) if (~fixed).any() else 0.0
+
+
+def make_compatible_stress_data(mesh, k, facet_type, seed=20241003):
+    """Two rows (G_r, f_r) of a synthetic stress problem that satisfy, for every free node a,
+    the force balance of each row, (f_r, hat_a) + (G_r, grad hat_a) = 0, AND the moment balance
+    (f_0, hat_a y) + (G_0, grad(hat_a y)) - (f_1, hat_a x) - (G_1, grad(hat_a x)) = 0
+    (what a P_k Galerkin elasticity solution, k >= 2, provides through the test functions
+    hat_a (y, -x)); the latter makes the weak-symmetry patch problems consistent.
+    Corrections: f_r -= c_r in P1, G += e [[0,1],[-1,0]] with e in P1 (sparse direct solve,
+    small meshes only).  Returns (flux_dg [2, ncells*nd*2], rhs_dg [2, ncells*nd])."""
+    if k < 2:
+        raise RuntimeError("Stress equilibration: RT_k with k>1 required!")
+    deg = k - 1
+    ft = np.asarray(facet_type).reshape(-1, mesh.nfacets)
+    data = [make_compatible_data(mesh, k, ft[r:r + 1], seed=seed + 17 * r) for r in range(2)]
+    dg = Lagrange(deg)
+    nd = dg.ndofs
+    G = np.stack([d[0].reshape(mesh.ncells, nd, 2) for d in data])
+    f = np.stack([d[1].reshape(mesh.ncells, nd) for d in data])
+    J, detJ, K = cell_geometry(mesh)
+    adet = np.abs(detJ)
+    qp, qw = make_quadrature_triangle(2 * deg + 4)
+    psi = dg.tabulate(qp)[0]
+    hat = Lagrange(1)
+    hq = hat.tabulate(qp, 1)
+    hv = hq[0]  # [q, n]
+    ghat_ref = np.stack([hq[1][0], hq[2][0]], axis=1)
+    ghat = np.einsum("cXd,nX->cnd", K, ghat_ref)  # [c, n, d]
+    x0 = mesh.x[mesh.cell_nodes[:, 0], :2]
+    xq = x0[:, None, :] + np.einsum("cij,qj->cqi", J, qp)  # [c, q, 2]
+    w = qw[None, :] * adet[:, None]  # [c, q]
+    cn = mesh.cell_nodes
+    nn = mesh.nnodes
+    fixed = np.zeros(nn, dtype=bool)
+    fixed[mesh.facet_nodes[ft[0] == 1].ravel()] = True
+    free = np.nonzero(~fixed)[0]
+
+    def assemble_vec(loc):  # loc [c, n]
+        r = np.zeros(nn)
+        np.add.at(r, cn.ravel(), loc.ravel())
+        return r
+
+    def assemble_mat(loc):  # loc [c, n(test a), m(trial b)]
+        rows = np.repeat(cn, 3, axis=1).ravel()
+        cols = np.tile(cn, (1, 3)).ravel()
+        return sp.csr_matrix((loc.ravel(), (rows, cols)), shape=(nn, nn))
+
+    fq = np.einsum("rcj,qj->rcq", f, psi)
+    Gq = np.einsum("rcjd,qj->rcqd", G, psi)
+    # moment residual: test function hat_a * (y, -x) -> rows (0: y, 1: -x)
+    X, Y = xq[..., 0], xq[..., 1]
+    # grad(hat_a y) = y grad hat_a + hat_a e_y ; grad(hat_a x) = x grad hat_a + hat_a e_x
+    r_rot = np.einsum("cq,cq,qn->cn", w, fq[0] * Y - fq[1] * X, hv) \
+        + np.einsum("cq,cqd,cnd->cn", w, Gq[0] * Y[..., None] - Gq[1] * X[..., None], ghat) \
+        + np.einsum("cq,cq,qn->cn", w, Gq[0][..., 1] - Gq[1][..., 0], hv)
+    R_rot = assemble_vec(r_rot)
+    # blocks of the 3-field system, unknowns (c0, c1, e), equations (R0, R1, Rrot) = 0
+    Mh = assemble_mat(np.einsum("cq,qn,qm->cnm", w, hv, hv))                      # (hat_b, hat_a)
+    My = assemble_mat(np.einsum("cq,cq,qn,qm->cnm", w, Y, hv, hv))                # (hat_b, hat_a y)
+    Mx = assemble_mat(np.einsum("cq,cq,qn,qm->cnm", w, X, hv, hv))
+    Dy = assemble_mat(np.einsum("cq,cn,qm->cnm", w, ghat[..., 1], hv))            # (hat_b, d_y hat_a)
+    Dx = assemble_mat(np.einsum("cq,cn,qm->cnm", w, ghat[..., 0], hv))
+    # (hat_b, 2 hat_a + x . grad hat_a)
+    Er = assemble_mat(2 * np.einsum("cq,qn,qm->cnm", w, hv, hv)
+                      + np.einsum("cq,cqd,cnd,qm->cnm", w, xq, ghat, hv))
+    Z = sp.csr_matrix((nn, nn))
+    # R0 + (-Mh c0) + (e, d_y hat_a) = 0 ; R1 + (-Mh c1) - (e, d_x hat_a) = 0
+    # Rrot + (-My c0) + (Mx c1) + Er e = 0      (R0 = R1 = 0 already)
+    A = sp.bmat([[-Mh, Z, Dy], [Z, -Mh, -Dx], [-My, Mx, Er]], format="csr")
+    idx = np.concatenate([free, nn + free, 2 * nn + free])
+    rhs = np.concatenate([np.zeros(2 * nn), -R_rot])[idx]
+    sol = spla.spsolve(A[idx][:, idx].tocsc(), rhs)
+    c0 = np.zeros(nn)
+    c1 = np.zeros(nn)
+    e = np.zeros(nn)
+    c0[free], c1[free], e[free] = np.split(sol, 3)
+    nodes = np.array([[float(a), float(b)] for a, b in dg.nodes])
+    hat_at_nodes = hat.tabulate(nodes)[0]  # [j, n]
+    f[0] -= np.einsum("jn,cn->cj", hat_at_nodes, c0[cn])
+    f[1] -= np.einsum("jn,cn->cj", hat_at_nodes, c1[cn])
+    e_dg = np.einsum("jn,cn->cj", hat_at_nodes, e[cn])
+    G[0][..., 1] += e_dg
+    G[1][..., 0] -= e_dg
+    return (np.ascontiguousarray(G.reshape(2, -1)), np.ascontiguousarray(f.reshape(2, -1)))

@@ -316,6 +316,46 @@ static void flux_dofmap_cell(patch_t* p, int a)
   }
 }
 
+/* DOFs of the patch-wise P1 multiplier space, se/Patch.hpp:595-708: per cell the slots
+ * offs[3] + {0: patch node, 1: outer node of E_a, 2: outer node of E_{a-1}}; patch-local ids:
+ * centre 0, outer node of E_a -> a; boundary patches: outer node of E_0 -> nfcts-1, of E_n -> nfcts */
+static int32_t facet_outer_node(const patch_t* p, int fct_i)
+{
+  const int32_t* fn = p->m->facet_nodes + 2 * (size_t)p->fcts[fct_i];
+  return (fn[0] == p->node) ? fn[1] : fn[0];
+}
+
+static void constraint_dofmap(patch_t* p)
+{
+  const int n = p->ncells, o = p->offs[3];
+  const int internal = (p->type[0] == PT_INTERNAL);
+  for (int a = 1; a <= n; ++a)
+  {
+    const int32_t cell = p->cells[a];
+    /* centre */
+    DM(p, 0, a, o) = p->inodes_local[a];
+    DM(p, 2, a, o) = 0;
+    DM(p, 3, a, o) = 1;
+    /* outer node of E_a (slot 1) and of E_{a-1} (slot 2) */
+    const int32_t node_ea = facet_outer_node(p, a);
+    const int32_t node_eam1 = facet_outer_node(p, a - 1);
+    DM(p, 0, a, o + 1) = node_local(p, cell, node_ea);
+    DM(p, 0, a, o + 2) = node_local(p, cell, node_eam1);
+    DM(p, 3, a, o + 1) = 1;
+    DM(p, 3, a, o + 2) = 1;
+    if (internal)
+    {
+      DM(p, 2, a, o + 1) = a;
+      DM(p, 2, a, o + 2) = (a == 1) ? n : a - 1;
+    }
+    else
+    {
+      DM(p, 2, a, o + 1) = (a == n) ? p->nfcts : a;
+      DM(p, 2, a, o + 2) = (a == 1) ? p->nfcts - 1 : a - 1;
+    }
+  }
+}
+
 /* se/Patch.hpp:792-898 */
 static void create_subdofmap(patch_t* p, int32_t node)
 {
@@ -324,6 +364,7 @@ static void create_subdofmap(patch_t* p, int32_t node)
   p->ndof_min_flux = 1 + (p->k - 1) * p->nfcts + p->nadd * n;
   for (int a = 1; a <= n; ++a)
     flux_dofmap_cell(p, a);
+  constraint_dofmap(p);
 }
 
 /* se/Patch.hpp:836-897: facet DOFs of the projected flux; needs the element table */
@@ -378,6 +419,11 @@ typedef struct
   double *c_ta_div, *cj_ta_ea;
   double *A, *Lc, *L, *u, *Te;
   int8_t* bmarkers;
+  /* weak symmetry (se/PatchData.hpp:118-157) */
+  int npnt_max, dim_c;
+  double *A_rec, *Bm, *Cm, *Lfull, *u_c, *AinvB, *u_sig2, *cstress, *Be, *Ce, *Le2;
+  int8_t* bmarkers2;
+  int meanvalue_required;
   double *G_Ta, *G_Tap1, *f_Ta;
   double* phi;       /* mapped RT basis [nq][ndofs][2] */
   double* rhs_cur;   /* mapped gradients [2][nq][nd] */
@@ -400,12 +446,12 @@ static void patch_alloc(patch_t* p, pdata_t* d, const oracle_mesh_t* m,
   p->ndf = tab->ndf;
   p->nadd = (k - 1) * (k - 2) / 2;
   p->ndiv = k * (k + 1) / 2 - 1;
-  p->ndofs_pc = 2 * k + p->nadd + p->ndiv;
+  p->ndofs_pc = 2 * k + p->nadd + 3 + p->ndiv; /* [E_am1 | E_a | add | constr (3) | div] */
   p->offs[0] = 0;
   p->offs[1] = k;
   p->offs[2] = 2 * k;
   p->offs[3] = 2 * k + p->nadd;
-  p->offs[4] = p->offs[3];
+  p->offs[4] = p->offs[3] + 3;
   int nmax = 0;
   for (int i = 0; i < m->nnodes; ++i)
   {
@@ -442,6 +488,19 @@ static void patch_alloc(patch_t* p, pdata_t* d, const oracle_mesh_t* m,
   d->u = xcalloc(d->dim_max, sizeof(double));
   d->Te = xcalloc((size_t)(d->nh + 1) * d->nh, sizeof(double));
   d->bmarkers = xcalloc(d->dim_max, 1);
+  d->npnt_max = nmax + 3;
+  d->A_rec = xcalloc((size_t)d->dim_max * d->dim_max, sizeof(double));
+  d->Bm = xcalloc((size_t)d->dim_max * 2 * d->npnt_max, sizeof(double));
+  d->Cm = xcalloc((size_t)(d->npnt_max + 1) * (d->npnt_max + 1), sizeof(double));
+  d->Lfull = xcalloc((size_t)2 * d->dim_max + d->npnt_max + 1, sizeof(double));
+  d->u_c = xcalloc(d->npnt_max + 1, sizeof(double));
+  d->AinvB = xcalloc((size_t)d->dim_max * d->npnt_max, sizeof(double));
+  d->u_sig2 = xcalloc((size_t)2 * d->dim_max, sizeof(double));
+  d->cstress = xcalloc((size_t)nmax * 2 * p->ndofs, sizeof(double));
+  d->Be = xcalloc((size_t)d->nh * 6, sizeof(double));
+  d->Ce = xcalloc(3, sizeof(double));
+  d->Le2 = xcalloc((size_t)2 * d->nh + 3, sizeof(double));
+  d->bmarkers2 = xcalloc((size_t)2 * d->dim_max, 1);
   d->G_Ta = xcalloc(2 * p->nd, sizeof(double));
   d->G_Tap1 = xcalloc(2 * p->nd, sizeof(double));
   d->f_Ta = xcalloc(p->nd, sizeof(double));
@@ -476,6 +535,18 @@ static void patch_free(patch_t* p, pdata_t* d)
   free(d->u);
   free(d->Te);
   free(d->bmarkers);
+  free(d->A_rec);
+  free(d->Bm);
+  free(d->Cm);
+  free(d->Lfull);
+  free(d->u_c);
+  free(d->AinvB);
+  free(d->u_sig2);
+  free(d->cstress);
+  free(d->Be);
+  free(d->Ce);
+  free(d->Le2);
+  free(d->bmarkers2);
   free(d->G_Ta);
   free(d->G_Tap1);
   free(d->f_Ta);
@@ -1184,6 +1255,344 @@ static int equilibrate_patch(patch_t* p, pdata_t* d, const oracle_tables_t* tab,
   return status;
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* Weak symmetry of the stress (rows 0 and 1), se/solve_patch_weaksym.hpp:59-233          */
+/* ------------------------------------------------------------------------------------ */
+
+/* generate_stress_minimisation_kernel, se/stressmin_kernel.hpp:76-248.  Te (as in the flux
+ * kernel) is written to d->Te when assemble_A; Be [nh][6], Ce [3], Le2 [2 nh + 3]. */
+static void stressmin_kernel(const patch_t* p, pdata_t* d, const oracle_tables_t* tab, int a,
+                             const double* coefficients /* [2][ndofs] */, int assemble_A)
+{
+  const int k = p->k, ndofs = p->ndofs, nh = d->nh, nq = tab->nq;
+  const int id_a = a - 1;
+  const double detJ = d->detJ[id_a];
+  const double* J = d->J + 4 * id_a;
+  const uint8_t eam1_reversed = d->reversed[2 * id_a];
+  const int offs_c = p->offs[3];
+  const int offs_Lc = 2 * nh;
+  if (assemble_A)
+    memset(d->Te, 0, sizeof(double) * (nh + 1) * nh);
+  memset(d->Be, 0, sizeof(double) * nh * 6);
+  memset(d->Ce, 0, sizeof(double) * 3);
+  memset(d->Le2, 0, sizeof(double) * (2 * nh + 3));
+
+  const double inv = 1.0 / detJ;
+  for (int q = 0; q < nq; ++q)
+    for (int i = 0; i < ndofs; ++i)
+    {
+      const double* r = tab->flux_basis + ((size_t)q * ndofs + i) * 2;
+      double* c = d->phi + ((size_t)q * ndofs + i) * 2;
+      c[0] = inv * J[0] * r[0] + inv * J[1] * r[1];
+      c[1] = inv * J[2] * r[0] + inv * J[3] * r[1];
+    }
+  const int ld0_eam1 = DM(p, 0, a, 0), ld0_ea = DM(p, 0, a, k);
+  const int p_eam1 = DM(p, 3, a, 0), p_ea = DM(p, 3, a, k);
+
+  for (int q = 0; q < nq; ++q)
+  {
+    double* phi = d->phi + (size_t)q * ndofs * 2;
+    double sig_r0[2] = {0, 0}, sig_r1[2] = {0, 0};
+    for (int i = 0; i < ndofs; ++i)
+    {
+      sig_r0[0] += coefficients[i] * phi[2 * i];
+      sig_r0[1] += coefficients[i] * phi[2 * i + 1];
+      sig_r1[0] += coefficients[ndofs + i] * phi[2 * i];
+      sig_r1[1] += coefficients[ndofs + i] * phi[2 * i + 1];
+    }
+    if (eam1_reversed)
+    {
+      memset(d->gphi, 0, sizeof(double) * 2 * k);
+      for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j)
+        {
+          int ldj = DM(p, 0, a, j);
+          d->gphi[2 * i] += tab->doftrafo[i * k + j] * phi[2 * ldj];
+          d->gphi[2 * i + 1] += tab->doftrafo[i * k + j] * phi[2 * ldj + 1];
+        }
+      for (int i = 0; i < k; ++i)
+      {
+        int ldi = DM(p, 0, a, i);
+        phi[2 * ldi] = d->gphi[2 * i];
+        phi[2 * ldi + 1] = d->gphi[2 * i + 1];
+      }
+    }
+    phi[2 * ld0_ea] = p_ea * (p_eam1 * phi[2 * ld0_eam1] + p_ea * phi[2 * ld0_ea]);
+    phi[2 * ld0_ea + 1] = p_ea * (p_eam1 * phi[2 * ld0_eam1 + 1] + p_ea * phi[2 * ld0_ea + 1]);
+
+    const double dvol = tab->qweights[q] * fabs(detJ);
+    for (int i = 0; i < nh; ++i)
+    {
+      const int ip1 = i + 1;
+      const int dl_i = DM(p, 0, a, ip1);
+      const double alpha = DM(p, 3, a, ip1) * dvol;
+      const double phi_i0 = phi[2 * dl_i] * alpha, phi_i1 = phi[2 * dl_i + 1] * alpha;
+      if (assemble_A)
+      {
+        d->Le2[i] -= sig_r0[0] * phi_i0 + sig_r0[1] * phi_i1;
+        d->Le2[nh + i] -= sig_r1[0] * phi_i0 + sig_r1[1] * phi_i1;
+        for (int j = i; j < nh; ++j)
+        {
+          const int jp1 = j + 1;
+          const int dl_j = DM(p, 0, a, jp1);
+          d->Te[i * nh + j] += phi_i0 * phi[2 * dl_j] * DM(p, 3, a, jp1)
+                               + phi_i1 * phi[2 * dl_j + 1] * DM(p, 3, a, jp1);
+        }
+      }
+      for (int j = 0; j < 3; ++j)
+      {
+        const double phi_j = tab->hat_cell[(size_t)q * 3 + DM(p, 0, a, offs_c + j)];
+        d->Be[i * 6 + j] += phi_i1 * phi_j;
+        d->Be[i * 6 + 3 + j] -= phi_i0 * phi_j;
+      }
+    }
+    for (int i = 0; i < 3; ++i)
+    {
+      const double phi_i = tab->hat_cell[(size_t)q * 3 + DM(p, 0, a, offs_c + i)] * dvol;
+      d->Ce[i] += phi_i;
+      d->Le2[offs_Lc + i] -= phi_i * (sig_r0[1] - sig_r1[0]);
+    }
+  }
+  if (assemble_A)
+    for (int i = 1; i < nh; ++i)
+      for (int j = 0; j < i; ++j)
+        d->Te[i * nh + j] = d->Te[j * nh + i];
+}
+
+/* Eigen::PartialPivLU stand-in: solve M x = b in place, M [n][ld] destroyed */
+static int lu_solve(double* M, int ld, int n, double* b)
+{
+  for (int c = 0; c < n; ++c)
+  {
+    int piv = c;
+    for (int r = c + 1; r < n; ++r)
+      if (fabs(M[r * ld + c]) > fabs(M[piv * ld + c]))
+        piv = r;
+    if (M[piv * ld + c] == 0.0)
+      return -2;
+    if (piv != c)
+    {
+      for (int j = 0; j < n; ++j)
+      {
+        double t = M[c * ld + j];
+        M[c * ld + j] = M[piv * ld + j];
+        M[piv * ld + j] = t;
+      }
+      double t = b[c];
+      b[c] = b[piv];
+      b[piv] = t;
+    }
+    for (int r = c + 1; r < n; ++r)
+    {
+      const double f = M[r * ld + c] / M[c * ld + c];
+      for (int j = c; j < n; ++j)
+        M[r * ld + j] -= f * M[c * ld + j];
+      b[r] -= f * b[c];
+    }
+  }
+  for (int r = n - 1; r >= 0; --r)
+  {
+    double t = b[r];
+    for (int j = r + 1; j < n; ++j)
+      t -= M[r * ld + j] * b[j];
+    b[r] = t / M[r * ld + r];
+  }
+  return 0;
+}
+
+/* impose_weak_symmetry<T,k,false>: assembly (se/assembly.hpp:292-472), Schur solve
+ * (se/PatchData.hpp:598-663), scatter (se/solve_patch_weaksym.hpp:189-232).
+ * Requires equilibrate_patch to have run for this patch (coefficients of rows 0, 1, mapping
+ * data, and - without flux BCs - the Cholesky factor of A). */
+static int impose_weak_symmetry(patch_t* p, pdata_t* d, const oracle_tables_t* tab,
+                                double* flux_hdiv)
+{
+  const int k = p->k, n = p->ncells, ndofs = p->ndofs, nh = d->nh, dm = d->dim_max;
+  const int gdim = 2;
+  const int dim = p->ndof_min_flux;
+  const int on_boundary = (p->type[0] != PT_INTERNAL);
+  const int npnt = p->nfcts + 1;
+  const int ldB = 2 * d->npnt_max, ldC = d->npnt_max + 1;
+  const size_t ncells_mesh = p->m->ncells;
+  int status = 0;
+
+  /* PatchData::reinitialisation :175-206 */
+  d->meanvalue_required = 1;
+  if (on_boundary)
+  {
+    int cnt = 0;
+    for (int i = 0; i < gdim; ++i)
+      if (p->type[i] == PT_ESSNT_PRIMAL || p->type[i] == PT_MIXED)
+        ++cnt;
+    if (cnt > 0)
+      d->meanvalue_required = 0;
+  }
+  int requires_bcs = 0;
+  int types[2] = {PT_INTERNAL, PT_INTERNAL}, revs[2] = {0, 0};
+  if (on_boundary)
+    for (int i = 0; i < gdim; ++i)
+    {
+      types[i] = p->type[i];
+      revs[i] = reversion_required(p, i);
+      if (types[i] == PT_ESSNT_DUAL || types[i] == PT_MIXED)
+        requires_bcs = 1;
+    }
+  /* stress coefficients = patch-local result of steps 1+2 :134-142 */
+  for (int r = 0; r < gdim; ++r)
+    for (int a = 1; a <= n; ++a)
+      memcpy(d->cstress + ((size_t)(a - 1) * gdim + r) * ndofs, &COEF(p, d, r, a - 1, 0), sizeof(double) * ndofs);
+  memset(d->bmarkers2, 0, 2 * dm);
+  if (on_boundary)
+    for (int i = 0; i < gdim; ++i)
+      set_boundary_markers(d->bmarkers2 + i * dim, dim, types[i], revs[i], n, k);
+  /* NB: set_boundary_markers of the reference handles all rows in one call with offset
+   * i*ndofs_hdivz (se/assembly.hpp:59-97); the two calls above are the same thing. */
+
+  if (requires_bcs)
+    memset(d->A_rec, 0, sizeof(double) * dm * dm);
+  memset(d->Bm, 0, sizeof(double) * dm * ldB);
+  memset(d->Cm, 0, sizeof(double) * ldC * ldC);
+  memset(d->Lfull, 0, sizeof(double) * (2 * dm + d->npnt_max + 1));
+  const int offs_c = p->offs[3];
+  for (int a = 1; a <= n; ++a)
+  {
+    stressmin_kernel(p, d, tab, a, d->cstress + (size_t)(a - 1) * gdim * ndofs, requires_bcs);
+    for (int kk = 0; kk < gdim; ++kk)
+    {
+      for (int i = 0; i < nh; ++i)
+      {
+        const int dof_i = DM(p, 2, a, i + 1);
+        if (requires_bcs)
+        {
+          d->Lfull[kk * dm + dof_i] += d->Le2[kk * nh + i];
+          if (kk == 0)
+            for (int j = 0; j < nh; ++j)
+              d->A_rec[dof_i * dm + DM(p, 2, a, j + 1)] += d->Te[i * nh + j];
+        }
+        for (int j = 0; j < 3; ++j)
+        {
+          const int dof_j = DM(p, 2, a, offs_c + j);
+          if (!requires_bcs || !d->bmarkers2[kk * dim + dof_i])
+            d->Bm[dof_i * ldB + kk * d->npnt_max + dof_j] += d->Be[i * 6 + kk * 3 + j];
+        }
+      }
+      if (kk == 0)
+        for (int i = 0; i < 3; ++i)
+        {
+          const int dof_i = DM(p, 2, a, offs_c + i);
+          if (d->meanvalue_required)
+          {
+            d->Cm[dof_i * ldC + npnt] += d->Ce[i];
+            d->Cm[npnt * ldC + dof_i] += d->Ce[i];
+          }
+          d->Lfull[2 * dm + dof_i] += d->Le2[2 * nh + i];
+        }
+    }
+  }
+
+  /* solve_constrained_minimisation, se/PatchData.hpp:598-663 */
+  for (int kk = 0; kk < gdim; ++kk)
+  {
+    if (requires_bcs)
+    {
+      /* apply_bcs_on_A :735-768 + factorise */
+      memset(d->A, 0, sizeof(double) * dm * dm);
+      for (int i = 0; i < dim; ++i)
+      {
+        if (d->bmarkers2[kk * dim + i])
+        {
+          d->Lfull[kk * dm + i] = 0.0;
+          d->A[i * dm + i] = 1.0;
+        }
+        else
+          for (int j = 0; j < dim; ++j)
+            d->A[i * dm + j] = d->bmarkers2[kk * dim + j] ? 0.0 : d->A_rec[i * dm + j];
+      }
+      if (k > 1 && factorise_A(d, dim))
+        status = -2;
+    }
+    for (int c = 0; c < npnt; ++c)
+    {
+      for (int i = 0; i < dim; ++i)
+        d->L[i] = d->Bm[i * ldB + kk * d->npnt_max + c];
+      if (k == 1)
+        d->u[0] = d->L[0] / d->A[0];
+      else
+        solve_A(d, dim);
+      for (int i = 0; i < dim; ++i)
+        d->AinvB[i * d->npnt_max + c] = d->u[i];
+    }
+    for (int r = 0; r < npnt; ++r)
+      for (int c = 0; c < npnt; ++c)
+      {
+        double t = 0.0;
+        for (int i = 0; i < dim; ++i)
+          t += d->Bm[i * ldB + kk * d->npnt_max + r] * d->AinvB[i * d->npnt_max + c];
+        d->Cm[r * ldC + c] -= t;
+      }
+  }
+  const int dim_c = d->meanvalue_required ? npnt + 1 : npnt;
+  for (int i = 0; i < dim_c; ++i)
+    d->u_c[i] = d->Lfull[2 * dm + i];
+  if (lu_solve(d->Cm, ldC, dim_c, d->u_c))
+    status = -2;
+  for (int kk = gdim - 1; kk >= 0; --kk)
+  {
+    if (requires_bcs && kk != gdim - 1)
+    {
+      memset(d->A, 0, sizeof(double) * dm * dm);
+      for (int i = 0; i < dim; ++i)
+      {
+        if (d->bmarkers2[kk * dim + i])
+          d->A[i * dm + i] = 1.0;
+        else
+          for (int j = 0; j < dim; ++j)
+            d->A[i * dm + j] = d->bmarkers2[kk * dim + j] ? 0.0 : d->A_rec[i * dm + j];
+      }
+      if (k > 1 && factorise_A(d, dim))
+        status = -2;
+    }
+    for (int i = 0; i < dim; ++i)
+    {
+      double t = 0.0;
+      for (int c = 0; c < npnt; ++c)
+        t -= d->Bm[i * ldB + kk * d->npnt_max + c] * d->u_c[c];
+      d->L[i] = t;
+    }
+    if (k == 1)
+      d->u[0] = d->L[0] / d->A[0];
+    else
+      solve_A(d, dim);
+    memcpy(d->u_sig2 + (size_t)kk * dm, d->u, sizeof(double) * dim);
+  }
+
+  /* scatter :189-232 */
+  const int ndofs_hdivz_per_cell = 2 * k + p->nadd;
+  for (int r = 0; r < gdim; ++r)
+  {
+    double* x = flux_hdiv + (size_t)r * ncells_mesh * ndofs;
+    const double* u = d->u_sig2 + (size_t)r * dm;
+    for (int a = 1; a <= n; ++a)
+    {
+      int start_j = 0;
+      if (d->reversed[2 * (a - 1)])
+      {
+        for (int j = 0; j < k; ++j)
+        {
+          double v = 0.0;
+          for (int kk = 0; kk < k; ++kk)
+            v += tab->doftrafo[kk * k + j] * DM(p, 3, a, kk) * u[DM(p, 2, a, kk)];
+          x[DM(p, 1, a, j)] += v;
+        }
+        start_j = k;
+      }
+      for (int j = start_j; j < ndofs_hdivz_per_cell; ++j)
+        x[DM(p, 1, a, j)] += DM(p, 3, a, j) * u[DM(p, 2, a, j)];
+    }
+  }
+  return status;
+}
+
 /* OrientedPatch::estimate_squared_korn_constant, se/Patch.cpp:130-334 (Kim's bound
  * 2 / sin^2(theta_min / 2) for star-shaped patches) */
 static double estimate_squared_korn_constant(const patch_t* p)
@@ -1385,10 +1794,38 @@ int oracle_build_patches(const oracle_mesh_t* mesh, int nrhs, const int8_t* face
   return 0;
 }
 
+static int se_reconstruct_impl(const oracle_mesh_t* mesh, const oracle_tables_t* tab, int nrhs,
+                               const int8_t* facet_type, const double* boundary_values,
+                               const double* flux_dg, const double* rhs_dg, double* flux_hdiv,
+                               int32_t node_begin, int32_t node_end, int stress);
+
 int oracle_se_reconstruct(const oracle_mesh_t* mesh, const oracle_tables_t* tab, int nrhs,
                           const int8_t* facet_type, const double* boundary_values,
                           const double* flux_dg, const double* rhs_dg, double* flux_hdiv,
                           int32_t node_begin, int32_t node_end)
+{
+  return se_reconstruct_impl(mesh, tab, nrhs, facet_type, boundary_values, flux_dg, rhs_dg,
+                             flux_hdiv, node_begin, node_end, 0);
+}
+
+/* se::reconstruction with reconstruct_stress = true, loop over "all other patches"
+ * (se/reconstruction.hpp:237-270); the grouped boundary patches of :170-234 (only with flux BCs
+ * on the stress and RT_2) are not restated. */
+int oracle_se_reconstruct_stress(const oracle_mesh_t* mesh, const oracle_tables_t* tab, int nrhs,
+                                 const int8_t* facet_type, const double* boundary_values,
+                                 const double* flux_dg, const double* rhs_dg, double* flux_hdiv,
+                                 int32_t node_begin, int32_t node_end)
+{
+  if (nrhs < 2 || tab->k < 2)
+    return -4; /* se/reconstruction.hpp:376-388 */
+  return se_reconstruct_impl(mesh, tab, nrhs, facet_type, boundary_values, flux_dg, rhs_dg,
+                             flux_hdiv, node_begin, node_end, 1);
+}
+
+static int se_reconstruct_impl(const oracle_mesh_t* mesh, const oracle_tables_t* tab, int nrhs,
+                               const int8_t* facet_type, const double* boundary_values,
+                               const double* flux_dg, const double* rhs_dg, double* flux_hdiv,
+                               int32_t node_begin, int32_t node_end, int stress)
 {
   /* OrientedPatch::set_max_patch_size, se/Patch.cpp:337-404 (ncells_min = 1): checks the
    * nodes the loop visits (size_local owned nodes in the reference) */
@@ -1408,6 +1845,12 @@ int oracle_se_reconstruct(const oracle_mesh_t* mesh, const oracle_tables_t* tab,
                                NULL, NULL);
     if (st)
       status = st;
+    if (stress)
+    {
+      st = impose_weak_symmetry(&p, &d, tab, flux_hdiv);
+      if (st)
+        status = st;
+    }
   }
   patch_free(&p, &d);
   return status;

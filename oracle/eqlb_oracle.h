@@ -82,6 +82,14 @@ int oracle_se_reconstruct(const oracle_mesh_t* mesh, const oracle_tables_t* tab,
                           const double* flux_dg, const double* rhs_dg, double* flux_hdiv,
                           int32_t node_begin, int32_t node_end);
 
+/* As oracle_se_reconstruct with reconstruct_stress = true: rows 0 and 1 are the rows of a stress
+ * tensor; after the row-wise equilibration each patch imposes the weak symmetry condition
+ * (se/solve_patch_weaksym.hpp:59-233).  returns -4 if nrhs < 2 or k < 2. */
+int oracle_se_reconstruct_stress(const oracle_mesh_t* mesh, const oracle_tables_t* tab, int nrhs,
+                                 const int8_t* facet_type, const double* boundary_values,
+                                 const double* flux_dg, const double* rhs_dg, double* flux_hdiv,
+                                 int32_t node_begin, int32_t node_end);
+
 /* Same, but only for the listed nodes and writing the per-patch result of the explicit
  * step (sigma-tilde) and of the full patch solve, for debugging/tests:
  *   out_patch [nrhs][ncells_patch][ndofs]  (ncells_patch of that node)               */

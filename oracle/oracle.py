@@ -54,6 +54,7 @@ def _load():
         _lib.oracle_se_patch.restype = C.c_int
         _lib.oracle_build_patches.restype = C.c_int
         _lib.oracle_se_korn.restype = C.c_int
+        _lib.oracle_se_reconstruct_stress.restype = C.c_int
     return _lib
 
 
@@ -96,7 +97,7 @@ def _prep(mesh, k, facet_type, flux_dg, rhs_dg, degree_dg):
 
 
 def se_reconstruct(mesh, k, facet_type, flux_dg, rhs_dg, boundary_values=None, degree_dg=None,
-                   flux_hdiv=None, node_range=None):
+                   flux_hdiv=None, node_range=None, stress=False):
     """Run the reference algorithm over all (or a range of) patches; returns flux_hdiv
     [nrhs, ncells*k(k+2)] (accumulated into `flux_hdiv` if given, like the reference)."""
     lib = _load()
@@ -109,9 +110,12 @@ def se_reconstruct(mesh, k, facet_type, flux_dg, rhs_dg, boundary_values=None, d
     if boundary_values is not None:
         boundary_values = np.ascontiguousarray(boundary_values, dtype=np.float64)
     nb, ne = node_range if node_range is not None else (0, mesh.nnodes)
-    st = lib.oracle_se_reconstruct(C.byref(ms), C.byref(ts), C.c_int(nrhs), _p(facet_type),
-                                   _p(boundary_values), _p(flux_dg), _p(rhs_dg), _p(flux_hdiv),
-                                   C.c_int32(nb), C.c_int32(ne))
+    fn = lib.oracle_se_reconstruct_stress if stress else lib.oracle_se_reconstruct
+    st = fn(C.byref(ms), C.byref(ts), C.c_int(nrhs), _p(facet_type),
+            _p(boundary_values), _p(flux_dg), _p(rhs_dg), _p(flux_hdiv),
+            C.c_int32(nb), C.c_int32(ne))
+    if st == -4:
+        raise RuntimeError("Stress equilibration: Specify all rows of stress tensor / RT_k with k>1")
     if st == -1:
         raise RuntimeError("Patch with only one cell")  # se/Patch.cpp:353-359
     if st != 0:

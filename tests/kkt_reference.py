@@ -32,8 +32,8 @@ def _geom(mesh, c):
     return J, detJ, np.linalg.inv(J)
 
 
-def solve_patch(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg=None):
-    """Returns (cells, coefficients[n, ndofs]) of the constrained minimiser on the patch."""
+def _system(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg=None):
+    """Constraint rows B, mass matrix M, right-hand side d of the patch problem."""
     degree_dg = k - 1 if degree_dg is None else degree_dg
     rt = ert.HierarchicRT(k)
     dg = Lagrange(degree_dg)
@@ -111,8 +111,12 @@ def solve_patch(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg=None):
                 val -= float(np.sum(w * s ** j * densG))
             add(row, val)
 
-    B = np.array(rows)
-    d = np.array(rhs)
+    return np.array(rows), M, np.array(rhs), cells, n, ndofs
+
+
+def solve_patch(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg=None):
+    """Returns (cells, coefficients[n, ndofs]) of the constrained minimiser on the patch."""
+    B, M, d, cells, n, ndofs = _system(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg)
     # particular solution + null space
     cp, *_ = np.linalg.lstsq(B, d, rcond=None)
     resid = np.linalg.norm(B @ cp - d)
@@ -121,3 +125,12 @@ def solve_patch(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg=None):
         y = np.linalg.solve(N.T @ M @ N, N.T @ M @ cp)
         cp = cp - N @ y
     return cells, cp.reshape(n, ndofs), resid, N.shape[1]
+
+
+def constraint_matrix(mesh, k, node, facet_type_row):
+    """(B, M): homogeneous constraint rows (i)-(iv) of the patch space and the block-diagonal
+    mass matrix, for one row of BC types (used by the weak-symmetry check)."""
+    nd = k * (k + 1) // 2
+    zG = np.zeros(mesh.ncells * nd * 2)
+    zf = np.zeros(mesh.ncells * nd)
+    return _system(mesh, k, node, facet_type_row, zG, zf)[:2]
