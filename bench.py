@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--solver", type=int, default=None)
     ap.add_argument("--scatter", type=int, default=None)
     ap.add_argument("--fused", type=int, default=1, help="all patch-size bins in one launch")
+    ap.add_argument("--stress", action="store_true",
+                    help="two rows + weak symmetry (BASELINE configs[3]); not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shuffle", type=int, default=None, help="seed for random local vertex order")
     return ap.parse_args()
@@ -77,9 +79,16 @@ def main():
     part = dd.StripPartition(n, rank, world, shuffle_seed=args.shuffle)
     mesh = part.mesh
     ft = part.facet_types()
-    G, f = make_compatible_data(mesh, k, ft, seed=20241003 + rank)
+    nrhs = 2 if args.stress else 1
+    if args.stress:
+        ft = np.repeat(ft, 2, axis=0)
+        rows = [make_compatible_data(mesh, k, ft[:1], seed=20241003 + rank + 17 * r) for r in range(2)]
+        G = np.stack([r_[0] for r_ in rows]).ravel()
+        f = np.stack([r_[1] for r_ in rows]).ravel()
+    else:
+        G, f = make_compatible_data(mesh, k, ft, seed=20241003 + rank)
     dmesh = cpp.DeviceMesh(mesh)
-    eq = cpp.SemiExplicitEquilibrator(dmesh, k, 1)
+    eq = cpp.SemiExplicitEquilibrator(dmesh, k, nrhs, reconstruct_stress=args.stress)
     if args.solver is not None:
         eq.set_option("solver", args.solver)
     if args.scatter is not None:
@@ -91,7 +100,7 @@ def main():
 
     d_G = torch.from_numpy(G).to(dev)
     d_f = torch.from_numpy(f).to(dev)
-    d_x = torch.zeros(mesh.ncells * nrt, dtype=torch.float64, device=dev)
+    d_x = torch.zeros(nrhs * mesh.ncells * nrt, dtype=torch.float64, device=dev)
     halo = dd.HaloExchange(part, nrt, dev) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -109,7 +118,7 @@ def main():
     torch.cuda.synchronize()
     x_host = d_x.cpu().numpy().copy()
     res = nrm = None
-    if world == 1:
+    if world == 1 and not args.stress:
         res, nrm = chk.divergence_residual(mesh, k, x_host, G, f)
 
     for _ in range(args.warmup):
@@ -171,7 +180,7 @@ def main():
             "workload": f"Poisson {4 * n * n} triangles per GPU (crossed unit square {n}x{n}), "
                         f"P{k} primal, FluxEqlbSE RT{k}, homogeneous Dirichlet, fp64",
             "patches_per_gpu": npatch_local, "cells_per_gpu": int(part.ncells_owned),
-            "nrhs": 1, "partition": "node-ownership strips" if world > 1 else "none",
+            "nrhs": nrhs, "weak_symmetry": bool(args.stress), "partition": "node-ownership strips" if world > 1 else "none",
             "solver": eq_solver_name(args.solver), "scatter": eq_scatter_name(args.scatter),
         },
         "roofline": {
@@ -189,7 +198,7 @@ def main():
         out["rhs_norm_L2"] = nrm
         out["div_residual_rel"] = res / nrm
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stress:
         out["cpu_baseline"] = cpu_baseline(mesh, k, ft, G, f, npatch_local)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -107,6 +107,7 @@ class SemiExplicitEquilibrator:
                  reconstruct_stress=False, estimate_korn=False):
         self.dmesh = dmesh
         self.k, self.nrhs = k, nrhs
+        self.reconstruct_stress = bool(reconstruct_stress)
         self.degree_dg = k - 1 if degree_dg is None else degree_dg
         self.nrt = k * (k + 2)
         self.nd = (self.degree_dg + 1) * (self.degree_dg + 2) // 2
@@ -237,6 +238,6 @@ def reconstruct_fluxes_semiexplt(flux_hdiv, flux_dg, rhs_dg, boundary_data, reco
     """Same name and argument order as the reference binding (wrappers.cpp:97-115); the
     arguments are flat arrays [nrhs, ...] and `boundary_data` is a configured
     SemiExplicitEquilibrator (it carries the facet types like base::BoundaryData does)."""
-    if reconstruct_stress:
-        raise RuntimeError("stress equilibration (weak symmetry) is not in this build")
+    if bool(reconstruct_stress) != bool(getattr(boundary_data, "reconstruct_stress", False)):
+        raise RuntimeError("reconstruct_stress does not match the equilibrator handle")
     return boundary_data.equilibrate_host(flux_dg, rhs_dg, flux_hdiv)

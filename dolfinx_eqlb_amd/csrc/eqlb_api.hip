@@ -172,7 +172,6 @@ int eqlb_se_create(eqlb_mesh_t* mesh, int32_t k, int32_t degree_dg, int32_t nrhs
                   "Stress equilibration: Specify all rows of stress tensor");
     if (k < 2)
       return fail(EQLB_ERR_INVALID_ARGUMENT, "Stress equilibration: RT_k with k>1 required!");
-    return fail(EQLB_ERR_UNSUPPORTED, "stress equilibration (weak symmetry) is not in this build");
   }
   (void)estimate_korn;
   std::vector<double> tab;
@@ -183,6 +182,7 @@ int eqlb_se_create(eqlb_mesh_t* mesh, int32_t k, int32_t degree_dg, int32_t nrhs
   h->k = k;
   h->deg = degree_dg;
   h->nrhs = nrhs;
+  h->stress = reconstruct_stress ? 1 : 0;
   h->nrt = k * (k + 2);
   h->nd = (degree_dg + 1) * (degree_dg + 2) / 2;
   int st = upload(&h->tables, tab.data(), tab.size());
@@ -575,6 +575,24 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
     }
     if (evs)
       HIP_TRY(hipEventRecord(evs[2 * b + 1], stream));
+  }
+  if (h->stress)
+  {
+    // weak symmetry of rows 0, 1 on the patch-local stresses held in the slots
+    // (se/reconstruction.hpp:237-270; grouped boundary patches :170-234 are not implemented)
+    if (h->scatter != EQLB_SCATTER_SLOTS)
+      return fail(EQLB_ERR_UNSUPPORTED, "stress equilibration needs the slot scatter");
+    for (int b = 0; b < eqlb::MAX_BINS; ++b)
+    {
+      if (h->bins[b].npatch == 0)
+        continue;
+      a.npatch = h->bins[b].npatch;
+      a.slot_offset = h->bins[b].slot_offset;
+      a.patch_offset = h->bins[b].patch_offset;
+      const int st = eqlb::launch_se_weaksym(h->k, h->bins[b].P, a, stream);
+      if (st)
+        return fail(st, "weak-symmetry kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
+    }
   }
   if (h->scatter == EQLB_SCATTER_SLOTS)
   {

@@ -101,6 +101,7 @@ int launch_se_patch(int k, int deg, int P, int solver, int scatter, const SeArgs
                     hipStream_t stream);
 int launch_se_patch_fused(int k, int deg, int scatter, const SeArgs& a, const FusedBins& fb,
                           hipStream_t stream);
+int launch_se_weaksym(int k, int P, const SeArgs& a, hipStream_t stream);
 void launch_reduce_slots(int nrt, int32_t ncells, int32_t nrhs, const double* slots, double* x,
                          hipStream_t stream);
 int projection_matrix_host(int degree, int nq, const double* pts, const double* wts,
@@ -123,7 +124,7 @@ struct eqlb_mesh
 struct eqlb_se
 {
   eqlb_mesh* mesh = nullptr;
-  int k = 0, deg = 0, nrhs = 0;
+  int k = 0, deg = 0, nrhs = 0, stress = 0;
   int nrt = 0, nd = 0;
   int solver = EQLB_SOLVER_SHUFFLE, scatter = EQLB_SCATTER_SLOTS, timing = 0, fused = 1;
   bool boundary_set = false;

@@ -18,28 +18,11 @@
 // Result scatter: SCATTER 0 writes each (cell, vertex) contribution once into a slot buffer that
 // a streaming kernel reduces in fixed order (bitwise reproducible); SCATTER 1 uses fp64 global
 // atomics.  DESIGN.md derives the formulation; tests/proto_gpu_math.py is its numpy statement.
-#include "eqlb_internal.h"
+#include "eqlb_device_common.h"
 #include "eqlb_tables_gen.h"
 
 namespace eqlb
 {
-
-// ---- compile-time sizes -----------------------------------------------------------------------
-__host__ __device__ constexpr int nd_of(int deg) { return (deg + 1) * (deg + 2) / 2; }
-__host__ __device__ constexpr int nrt_of(int k) { return k * (k + 2); }
-__host__ __device__ constexpr int nq_of(int k) { return k * (k + 1) / 2; }
-__host__ __device__ constexpr int binom(int n, int r)
-{
-  int v = 1;
-  for (int i = 0; i < r; ++i)
-    v = v * (n - i) / (i + 1);
-  return v;
-}
-// B_ji = C(j,i)(-1)^i : moments w.r.t. s of a trace known by its moments w.r.t. 1-s
-__host__ __device__ constexpr double bcoef(int j, int i)
-{
-  return (i > j) ? 0.0 : ((i % 2 == 0) ? 1.0 : -1.0) * binom(j, i);
-}
 
 size_t table_doubles(int k, int deg)
 {
@@ -47,7 +30,8 @@ size_t table_doubles(int k, int deg)
   const int kb = k - 1, nadd = (k - 1) * (k - 2) / 2, ndiv = k * (k + 1) / 2 - 1;
   const int nh = 1 + 2 * kb + nadd, ncol = 2 * k + ndiv;
   return (size_t)3 * nrt * nrt + (size_t)9 * nd * k + (size_t)3 * nd * nq + (size_t)6 * nd * nq
-         + (size_t)18 * 3 * (nh * (nh + 1) / 2) + (size_t)18 * 3 * nh * ncol;
+         + (size_t)18 * 3 * (nh * (nh + 1) / 2) + (size_t)18 * 3 * nh * ncol
+         + (size_t)3 * nrt * 2 + (size_t)18 * 2 * nh * 3;
 }
 
 template <int K, int DEG>
@@ -61,6 +45,8 @@ static void fill_tables_t(std::vector<double>& out)
   out.insert(out.end(), R::D, R::D + R::D_SIZE);
   out.insert(out.end(), R::TE, R::TE + R::TE_SIZE);
   out.insert(out.end(), R::WQ, R::WQ + R::WQ_SIZE);
+  out.insert(out.end(), R::V, R::V + R::V_SIZE);
+  out.insert(out.end(), R::VQ, R::VQ + R::VQ_SIZE);
 }
 
 int fill_tables_host(int k, int deg, std::vector<double>& out)
@@ -82,21 +68,6 @@ int fill_tables_host(int k, int deg, std::vector<double>& out)
   return (out.size() == table_doubles(k, deg)) ? 0 : EQLB_ERR_UNSUPPORTED;
 }
 
-// ---- wave-level helpers -----------------------------------------------------------------------
-// LDS traffic between lanes of ONE wave: DS operations of a wave execute in order, the fences
-// keep the compiler from moving accesses across the hand-off.
-__device__ __forceinline__ void wave_sync()
-{
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ double shfl_d(double v, int src_lane) { return __shfl(v, src_lane, 64); }
-
-__device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; } // i >= j
-
-
 // A/B switches of the memory path: cooperative LDS staging of the input
 // rows (LDS-DMA) and of the output slot rows
 #ifndef EQLB_STAGE_IN
@@ -107,44 +78,6 @@ __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 #endif
 
 // ---- the patch kernel ---------------------------------------------------------------------------
-template <int K, int DEG, int P>
-struct Sizes
-{
-  static constexpr int KB = K - 1;
-  static constexpr int NADD = (K - 1) * (K - 2) / 2;
-  static constexpr int NDIV = K * (K + 1) / 2 - 1;
-  static constexpr int NRT = nrt_of(K), ND = nd_of(DEG), NQ = nq_of(K);
-  static constexpr int NY = 2 * K + NADD;      // own-frame unknowns of a cell: mu_m, mu_p, add
-  static constexpr int NCOL = 2 * K + NDIV;    // columns of the load tensor: mu_m, mu_p, div DOFs
-  static constexpr int NH = 1 + 2 * KB + NADD; // local unknowns [d | um | up | ua]
-  static constexpr int NTE = NH * (NH + 1) / 2;
-  static constexpr int DIMMAX = 1 + KB * P + NADD * P;
-  static constexpr int TRI = DIMMAX * (DIMMAX + 1) / 2;
-  static constexpr int LDS_GROUP = TRI + DIMMAX; // doubles per patch for SOLVER 0
-  // device table buffer: S | F | H | D | TE | WQ ; the kernel stages everything behind S in LDS
-  static constexpr int NS = 3 * NRT * NRT, NF = 9 * ND * K, NHT = 3 * ND * NQ, NDT = 6 * ND * NQ;
-  static constexpr int NTET = 18 * 3 * NTE, NWQT = 18 * 3 * NH * NCOL;
-  static constexpr int NTAB = NF + NHT + NDT + NTET + NWQT;
-  // workgroup size: as many waves as fit a 64 KiB LDS budget for the dense tiles (at least one)
-  // per-wave staging of the gathered input rows (G, f, J of 64 cells) / the output rows
-  static constexpr int FB = ((8 * ND) % 16 == 0) ? 16 : 4; // f-row piece (LDS-DMA: 16 or 4 bytes)
-  static constexpr int NCF = 8 * ND / FB;
-  static constexpr int STG_G = 64 * ND * 2, STG_F = 64 * ND, STG_J = 64 * 4;
-  static constexpr int STG_IN = STG_G + STG_F + STG_J, STG_OUT = 64 * NRT;
-  static constexpr int STG = (STG_IN > STG_OUT) ? STG_IN : STG_OUT;
-  static constexpr int lds_doubles(int block, int solver)
-  {
-    return NTAB + (block / 64) * STG + ((K > 1 && solver == 0) ? (block / P) * LDS_GROUP : 0);
-  }
-  static constexpr int block_of(int solver)
-  {
-    return (P >= 32) ? 64
-                     : ((lds_doubles(256, solver) * 8 <= 65536)
-                            ? 256
-                            : ((lds_doubles(128, solver) * 8 <= 65536) ? 128 : 64));
-  }
-};
-
 template <int K, int DEG, int P, int SOLVER, int SCATTER, int BLOCK>
 __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t block_id, double* lds)
 {

@@ -1,0 +1,476 @@
+// Weak symmetry of equilibrated stresses on gfx950: impose_weak_symmetry
+// (cpp/dolfinx_eqlb/se/solve_patch_weaksym.hpp:59-233) with assemble_stressminimiser
+// (se/assembly.hpp:292-472), the kernel of se/stressmin_kernel.hpp:76-248 and the Schur solve
+// PatchData::solve_constrained_minimisation (se/PatchData.hpp:598-663).
+//
+// Runs after the row-wise flux kernels: the slot buffer then holds exactly the patch-local stress
+// rows sigma_a (one slot row per (cell, vertex)), which is what the reference feeds into the
+// constrained minimisation (:134-142).  Per patch (P lanes, one per cell, as in k_se_patch):
+//   saddle system  [A 0 B0; 0 A B1; B0^T B1^T 0(+mean-value row)] [u0; u1; gamma] = [0; 0; Lc]
+//   B0(i,j) = int (Phi_i)_y psi_j,  B1(i,j) = -int (Phi_i)_x psi_j,  Lc(j) = -int psi_j (s01 - s10)
+// over the patch-wise H(div=0) functions Phi_i and the patch P1 functions psi_j.  Quadrature-free:
+// Phi/psi products are contractions with the constant tensors V, VQ (tools/gen_tables.py).
+// Solve: Cholesky A = L L^T in LDS, Y_k = L^-1 B_k (one column per lane, no synchronisation),
+// Schur complement C = -sum_k Y_k^T Y_k (+ multiplier row), dense LU with partial pivoting of the
+// (npnt+1)^2 system, u_k = -L^-T (Y_k gamma); the corrections are added to the slot rows in place.
+// With flux BCs on a stress row the masked A (and B rows) of that row are used (:611-656).
+#include "eqlb_device_common.h"
+#include "eqlb_tables_gen.h"
+
+namespace eqlb
+{
+
+template <int K, int P>
+struct WsSizes
+{
+  using Z = Sizes<K, K - 1, P>;
+  static constexpr int KB = Z::KB, NADD = Z::NADD, NH = Z::NH, NRT = Z::NRT, NTE = Z::NTE;
+  static constexpr int DIMMAX = Z::DIMMAX;      // H(div=0) unknowns of a patch
+  static constexpr int NPMAX = P + 2;           // patch nodes (multiplier DOFs)
+  static constexpr int DCMAX = NPMAX + 1;       // + mean-value multiplier
+  static constexpr int TRI = DIMMAX * (DIMMAX + 1) / 2;
+  // per patch: A0, A1 (packed lower) | Y [DIMMAX][2*NPMAX] | C [DCMAX][DCMAX] | rhs_c [DCMAX] | w [2][DIMMAX]
+  static constexpr int OFF_A1 = TRI, OFF_Y = 2 * TRI, OFF_C = OFF_Y + DIMMAX * 2 * NPMAX;
+  static constexpr int OFF_R = OFF_C + DCMAX * DCMAX, OFF_W = OFF_R + DCMAX;
+  static constexpr int GROUP = OFF_W + 2 * DIMMAX;
+  static constexpr int NTAB = Z::NTET + Z::NVT + Z::NVQT; // TE | V | VQ
+  static constexpr int BLOCK = 64;
+  static constexpr int lds_doubles() { return NTAB + (BLOCK / P) * GROUP; }
+};
+
+template <int K, int P>
+__global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
+{
+  using W = WsSizes<K, P>;
+  using Z = typename W::Z;
+  constexpr int KB = W::KB, NADD = W::NADD, NH = W::NH, NRT = W::NRT, NTE = W::NTE;
+  constexpr int NPMAX = W::NPMAX, DCMAX = W::DCMAX, LDY = 2 * W::NPMAX;
+
+  extern __shared__ double lds[];
+  double* sTE = lds;
+  double* sV = sTE + Z::NTET;
+  double* sVQ = sV + Z::NVT;
+  double* sG = sVQ + Z::NVQT;
+
+  const int tid = threadIdx.x;
+  for (int i = tid; i < Z::NTET; i += W::BLOCK)
+    sTE[i] = a.tables[Z::OFF_TE + i];
+  for (int i = tid; i < Z::NVT + Z::NVQT; i += W::BLOCK)
+    sV[i] = a.tables[Z::OFF_V + i];
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int sub = lane % P;
+  const int64_t patch_local = ((int64_t)blockIdx.x * W::BLOCK + tid) / P;
+  const bool pvalid = patch_local < a.npatch;
+  const int64_t slot = a.slot_offset + patch_local * P + sub;
+  const int64_t patch = a.patch_offset + patch_local;
+  const int n = pvalid ? (int)a.pn[patch] : 0;
+  const bool active = pvalid && sub < n;
+  const int32_t cell = active ? a.slot_cell[slot] : 0;
+  const uint32_t info = active ? a.slot_info[slot] : 0u;
+  const int fm = (info >> INFO_FM_SHIFT) & 3, fp = (info >> INFO_FP_SHIFT) & 3;
+  const int ln = (info >> INFO_LN_SHIFT) & 3;
+  const bool rev_m = (info & INFO_REV_M) != 0;
+  const int ci = (fm * 3 + fp) * 2 + (rev_m ? 1 : 0);
+
+  double J[2][2] = {{1.0, 0.0}, {0.0, 1.0}};
+  if (active)
+  {
+    const double2* Jp = reinterpret_cast<const double2*>(a.cellJ + 4 * (int64_t)cell);
+    const double2 j0 = Jp[0], j1 = Jp[1];
+    J[0][0] = j0.x;
+    J[0][1] = j0.y;
+    J[1][0] = j1.x;
+    J[1][1] = j1.y;
+  }
+  const double detJ = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+  const double sgn = (detJ > 0.0) ? 1.0 : -1.0;
+  const double pf_m = (fm == 1) ? sgn : -sgn, pf_p = (fp == 1) ? sgn : -sgn;
+
+  const uint8_t flag0 = pvalid ? a.pflag[patch] : (uint8_t)PFLAG_INTERIOR;
+  const uint8_t flag1 = pvalid ? a.pflag[a.npatch_total + patch] : (uint8_t)PFLAG_INTERIOR;
+  const bool interior = (flag0 & PFLAG_INTERIOR) != 0;
+  const int nf = interior ? n : n + 1;
+  const int nn = (n > 0) ? n : 1;
+  const int fi_p = interior ? ((sub + 1 < nn) ? sub + 1 : 0) : sub + 1;
+  const int dim = pvalid ? 1 + KB * nf + NADD * n : 0;
+  const int npnt = nf + 1;
+  // flux BCs of the two rows (bits as in k_se_patch); PatchData::reinitialisation :175-206
+  const bool bc0[2] = {(flag0 & PFLAG_BC0) != 0, (flag1 & PFLAG_BC0) != 0};
+  const bool bcn[2] = {(flag0 & PFLAG_BCN) != 0, (flag1 & PFLAG_BCN) != 0};
+  const bool requires_bcs = bc0[0] || bcn[0] || bc0[1] || bcn[1];
+  // mean-value multiplier unless some row has a primal-Dirichlet end (type essnt_primal or mixed)
+  const bool row_dual[2] = {!interior && bc0[0] && bcn[0], !interior && bc0[1] && bcn[1]};
+  const bool meanvalue = interior || (row_dual[0] && row_dual[1]);
+  const int dim_c = meanvalue ? npnt + 1 : npnt;
+
+  double* Ag = sG + (tid / P) * W::GROUP; // A of row 0 (and of both rows without flux BCs)
+  double* Yg = Ag + W::OFF_Y;
+  double* Cg = Ag + W::OFF_C;
+  double* Rg = Ag + W::OFF_R;
+  double* Wg = Ag + W::OFF_W;
+
+  // ---- element quantities ----
+  double Te[NH][NH];
+  {
+    const double ia = active ? 1.0 / fabs(detJ) : 0.0;
+    const double g0 = (J[0][0] * J[0][0] + J[1][0] * J[1][0]) * ia,
+                 g1 = (J[0][0] * J[0][1] + J[1][0] * J[1][1]) * ia,
+                 g2 = (J[0][1] * J[0][1] + J[1][1] * J[1][1]) * ia;
+    const double* te = sTE + ci * 3 * NTE;
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int g = 0; g <= h; ++g)
+      {
+        const int e = h * (h + 1) / 2 + g;
+        const double v = g0 * te[e] + g1 * te[NTE + e] + g2 * te[2 * NTE + e];
+        Te[h][g] = v;
+        Te[g][h] = v;
+      }
+  }
+  // Be[k][h][j]: k = 0: int (Phi_h)_y psi_j ; k = 1: -int (Phi_h)_x psi_j
+  double Be[2][NH][3];
+  {
+    const double* vq = sVQ + ci * 2 * NH * 3;
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+      {
+        const double v0 = vq[h * 3 + j], v1 = vq[(NH + h) * 3 + j]; // X = 0, 1
+        Be[0][h][j] = active ? (J[1][0] * v0 + J[1][1] * v1) : 0.0;
+        Be[1][h][j] = active ? -(J[0][0] * v0 + J[0][1] * v1) : 0.0;
+      }
+  }
+  // patch-local stress rows from the slots; Lc_e[j] = -int psi_j (s01 - s10), Ce = |detJ|/6
+  double* srow[2] = {nullptr, nullptr};
+  double Lce[3] = {0.0, 0.0, 0.0};
+  if (active)
+  {
+    srow[0] = a.out + (((int64_t)0 * a.ncells + cell) * 3 + ln) * NRT;
+    srow[1] = a.out + (((int64_t)1 * a.ncells + cell) * 3 + ln) * NRT;
+#pragma unroll
+    for (int i = 0; i < NRT; ++i)
+    {
+      const double c0 = srow[0][i], c1 = srow[1][i];
+      const double w0 = c0 * J[1][0] - c1 * J[0][0], w1 = c0 * J[1][1] - c1 * J[0][1];
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        Lce[j] -= sgn * (w0 * sV[(j * NRT + i) * 2] + w1 * sV[(j * NRT + i) * 2 + 1]);
+    }
+  }
+  const double Ce = active ? fabs(detJ) / 6.0 : 0.0;
+
+  // ---- numbering ----
+  int gi[NH];
+  gi[0] = 0;
+#pragma unroll
+  for (int j = 0; j < KB; ++j)
+  {
+    gi[1 + j] = 1 + sub * KB + j;
+    gi[1 + KB + j] = 1 + fi_p * KB + j;
+  }
+#pragma unroll
+  for (int q = 0; q < NADD; ++q)
+    gi[1 + 2 * KB + q] = 1 + nf * KB + sub * NADD + q;
+  // multiplier DOF of the cell's local vertex j (se/Patch.hpp:621-708)
+  int pj[3];
+  {
+    const int v_ea = 3 - fp - ln, v_eam1 = 3 - fm - ln;
+    const int p_ea = interior ? sub + 1 : ((sub + 1 == n) ? nf : sub + 1);
+    const int p_eam1 = interior ? ((sub == 0) ? n : sub) : ((sub == 0) ? nf - 1 : sub);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      pj[j] = (j == ln) ? 0 : ((j == v_ea) ? p_ea : ((j == v_eam1) ? p_eam1 : 0));
+  }
+  // fixed (flux-BC) unknowns per row k (se/assembly.hpp:46-98): local unknown h of this lane
+  auto fixed = [&](int k, int h) {
+    const bool dfx = bc0[k] || bcn[k];
+    if (h == 0)
+      return dfx;
+    if (h <= KB)
+      return bc0[k] && sub == 0;
+    if (h <= 2 * KB)
+      return bcn[k] && sub == n - 1;
+    return false;
+  };
+
+  // ---- zero the tile ----
+  for (int e = sub; e < W::GROUP; e += P)
+    Ag[e] = 0.0;
+  wave_sync();
+
+  // ---- assembly: A (per row if masked), B, C column, Lc  (LDS atomics: entries are shared by
+  //      neighbouring cells; the addition order is fixed by the lane order) ----
+  if (active)
+  {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+    {
+      if (k == 1 && !requires_bcs)
+        break;
+      double* Ak = Ag + k * W::OFF_A1;
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+      {
+        if (fixed(k, h) && requires_bcs)
+          continue;
+#pragma unroll
+        for (int g = 0; g < NH; ++g)
+          if (gi[h] >= gi[g] && !(fixed(k, g) && requires_bcs))
+            atomicAdd(&Ak[tri(gi[h], gi[g])], Te[h][g]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+      {
+        if (fixed(k, h) && requires_bcs)
+          continue; // rows of fixed unknowns are dropped (se/assembly.hpp:430-436)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          atomicAdd(&Yg[gi[h] * LDY + k * NPMAX + pj[j]], Be[k][h][j]);
+      }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+    {
+      atomicAdd(&Rg[pj[j]], Lce[j]);
+      if (meanvalue)
+      {
+        atomicAdd(&Cg[pj[j] * DCMAX + npnt], Ce);
+        atomicAdd(&Cg[npnt * DCMAX + pj[j]], Ce);
+      }
+    }
+  }
+  wave_sync();
+  // identity rows of the fixed unknowns
+  if (requires_bcs && sub == 0 && pvalid)
+  {
+    for (int k = 0; k < 2; ++k)
+    {
+      double* Ak = Ag + k * W::OFF_A1;
+      if (bc0[k] || bcn[k])
+        Ak[0] = 1.0;
+      if (bc0[k])
+        for (int j = 0; j < KB; ++j)
+          Ak[tri(1 + j, 1 + j)] = 1.0;
+      if (bcn[k])
+        for (int j = 0; j < KB; ++j)
+          Ak[tri(1 + n * KB + j, 1 + n * KB + j)] = 1.0;
+    }
+  }
+  wave_sync();
+
+  int status_local = 0;
+  // ---- Cholesky of A (both rows if masked) ----
+  for (int k = 0; k < 2; ++k)
+  {
+    if (k == 1 && !requires_bcs)
+      break;
+    double* Ak = Ag + k * W::OFF_A1;
+    for (int j = 0; j < dim; ++j)
+    {
+      const double ajj = Ak[tri(j, j)];
+      if (!(ajj > 0.0))
+        status_local = 1;
+      const double ljj = sqrt(ajj > 0.0 ? ajj : 1.0);
+      const double inv = 1.0 / ljj;
+      wave_sync();
+      for (int i = j + sub; i < dim; i += P)
+        Ak[tri(i, j)] = (i == j) ? ljj : Ak[tri(i, j)] * inv;
+      wave_sync();
+      for (int i = j + 1 + sub; i < dim; i += P)
+      {
+        const double lij = Ak[tri(i, j)];
+        for (int kk = j + 1; kk <= i; ++kk)
+          Ak[tri(i, kk)] -= lij * Ak[tri(kk, j)];
+      }
+      wave_sync();
+    }
+  }
+  // ---- Y_k = L_k^-1 B_k: every lane forward-substitutes whole columns ----
+  for (int col = sub; col < 2 * npnt; col += P)
+  {
+    const int k = col / npnt, c = col - k * npnt;
+    const double* Ak = Ag + ((requires_bcs && k == 1) ? W::OFF_A1 : 0);
+    double* y = Yg + k * NPMAX + c;
+    for (int i = 0; i < dim; ++i)
+    {
+      double t = y[i * LDY];
+      for (int q = 0; q < i; ++q)
+        t -= Ak[tri(i, q)] * y[q * LDY];
+      y[i * LDY] = t / Ak[tri(i, i)];
+    }
+  }
+  wave_sync();
+  // ---- Schur complement C -= sum_k Y_k^T Y_k ----
+  for (int e = sub; e < npnt * npnt; e += P)
+  {
+    const int r = e / npnt, c = e - r * npnt;
+    double t = 0.0;
+    for (int k = 0; k < 2; ++k)
+      for (int i = 0; i < dim; ++i)
+        t += Yg[i * LDY + k * NPMAX + r] * Yg[i * LDY + k * NPMAX + c];
+    Cg[r * DCMAX + c] -= t;
+  }
+  wave_sync();
+  // ---- dense LU with partial pivoting (one lane per patch; <= (P+3)^2 entries) ----
+  if (sub == 0 && pvalid)
+  {
+    for (int c = 0; c < dim_c; ++c)
+    {
+      int piv = c;
+      double best = fabs(Cg[c * DCMAX + c]);
+      for (int r = c + 1; r < dim_c; ++r)
+      {
+        const double v = fabs(Cg[r * DCMAX + c]);
+        if (v > best)
+        {
+          best = v;
+          piv = r;
+        }
+      }
+      if (best == 0.0)
+      {
+        status_local = 1;
+        continue;
+      }
+      if (piv != c)
+      {
+        for (int j = 0; j < dim_c; ++j)
+        {
+          const double t = Cg[c * DCMAX + j];
+          Cg[c * DCMAX + j] = Cg[piv * DCMAX + j];
+          Cg[piv * DCMAX + j] = t;
+        }
+        const double t = Rg[c];
+        Rg[c] = Rg[piv];
+        Rg[piv] = t;
+      }
+      const double ip = 1.0 / Cg[c * DCMAX + c];
+      for (int r = c + 1; r < dim_c; ++r)
+      {
+        const double f = Cg[r * DCMAX + c] * ip;
+        for (int j = c; j < dim_c; ++j)
+          Cg[r * DCMAX + j] -= f * Cg[c * DCMAX + j];
+        Rg[r] -= f * Rg[c];
+      }
+    }
+    for (int r = dim_c - 1; r >= 0; --r)
+    {
+      double t = Rg[r];
+      for (int j = r + 1; j < dim_c; ++j)
+        t -= Cg[r * DCMAX + j] * Rg[j];
+      Rg[r] = t / Cg[r * DCMAX + r];
+    }
+  }
+  wave_sync();
+  // ---- u_k = -L_k^-T (Y_k gamma) ----
+  for (int e = sub; e < 2 * dim; e += P)
+  {
+    const int k = e / dim, i = e - k * dim;
+    double t = 0.0;
+    for (int c = 0; c < npnt; ++c)
+      t -= Yg[i * LDY + k * NPMAX + c] * Rg[c];
+    Wg[k * W::DIMMAX + i] = t;
+  }
+  wave_sync();
+  if (sub < 2 && pvalid)
+  {
+    const int k = sub;
+    const double* Ak = Ag + ((requires_bcs && k == 1) ? W::OFF_A1 : 0);
+    double* w = Wg + k * W::DIMMAX;
+    for (int i = dim - 1; i >= 0; --i)
+    {
+      double t = w[i];
+      for (int q = i + 1; q < dim; ++q)
+        t -= Ak[tri(q, i)] * w[q];
+      w[i] = t / Ak[tri(i, i)];
+    }
+  }
+  wave_sync();
+
+  // ---- back-map and add to the slot rows (se/solve_patch_weaksym.hpp:189-232) ----
+  if (active)
+  {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+    {
+      const double* w = Wg + k * W::DIMMAX;
+      double ul[NH];
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+        ul[h] = w[gi[h]];
+      double* o = srow[k];
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+      {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < K; ++c)
+          s -= (rev_m ? bcoef(j, c) : ((j == c) ? 1.0 : 0.0)) * ul[c];
+        const double yp = (j == 0) ? ul[0] : ul[KB + j];
+        o[fm * K + j] += pf_m * s;
+        o[fp * K + j] += pf_p * yp;
+      }
+#pragma unroll
+      for (int q = 0; q < NADD; ++q)
+        o[3 * K + Z::NDIV + q] += sgn * ul[1 + 2 * KB + q];
+    }
+  }
+  if (status_local)
+    atomicOr(a.status, 2);
+}
+
+template <int K, int P>
+static int launch_ws_t(const SeArgs& a, hipStream_t stream)
+{
+  using W = WsSizes<K, P>;
+  const size_t lds_bytes = sizeof(double) * (size_t)W::lds_doubles();
+  if (lds_bytes > 160 * 1024)
+    return EQLB_ERR_UNSUPPORTED;
+  auto kern = k_se_weaksym<K, P>;
+  if (lds_bytes > 64 * 1024)
+  {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
+        != hipSuccess)
+      return EQLB_ERR_DEVICE;
+  }
+  const int64_t grid = (a.npatch * P + W::BLOCK - 1) / W::BLOCK;
+  if (grid == 0)
+    return 0;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(W::BLOCK), lds_bytes, stream, a);
+  return (hipGetLastError() == hipSuccess) ? 0 : EQLB_ERR_DEVICE;
+}
+
+template <int K>
+static int launch_ws_k(int P, const SeArgs& a, hipStream_t stream)
+{
+  switch (P)
+  {
+  case 4:
+    return launch_ws_t<K, 4>(a, stream);
+  case 8:
+    return launch_ws_t<K, 8>(a, stream);
+  case 16:
+    return launch_ws_t<K, 16>(a, stream);
+  case 32:
+    return launch_ws_t<K, 32>(a, stream);
+  }
+  return EQLB_ERR_UNSUPPORTED; // patches with more than 31 cells: tile does not fit LDS
+}
+
+int launch_se_weaksym(int k, int P, const SeArgs& a, hipStream_t stream)
+{
+  if (k == 2)
+    return launch_ws_k<2>(P, a, stream);
+  if (k == 3)
+    return launch_ws_k<3>(P, a, stream);
+  return EQLB_ERR_UNSUPPORTED;
+}
+
+} // namespace eqlb

@@ -87,8 +87,11 @@ void eqlb_mesh_destroy(eqlb_mesh_t* mesh);
  * Replaces the per-call setup of se::reconstruction<T,k> (se/reconstruction.hpp:62-163:
  * KernelData tabulation, kernel generation, Patch/PatchData allocation) - done once here and
  * cached on the device.  reconstruct_stress / korn are the flags of
- * reconstruct_fluxes_semiexplt[_with_kornconst] (wrappers.cpp:97-137); stress equilibration
- * is not in this build (EQLB_ERR_UNSUPPORTED); estimate_korn is accepted for symmetry with the
+ * reconstruct_fluxes_semiexplt[_with_kornconst] (wrappers.cpp:97-137).  reconstruct_stress != 0:
+ * the first two RHS are the rows of a stress tensor and the weak symmetry condition is imposed
+ * patch-wise after the row-wise equilibration (se/solve_patch_weaksym.hpp:59-233); the grouped
+ * boundary patches for RT_2 with flux BCs on the stress (se/reconstruction.hpp:170-234) are not
+ * in this build.  estimate_korn is accepted for symmetry with the
  * reference constructor (the estimate itself is requested per call, see below).
  */
 int eqlb_se_create(eqlb_mesh_t* mesh, int32_t k, int32_t degree_dg, int32_t nrhs,

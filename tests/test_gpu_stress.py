@@ -1,0 +1,33 @@
+"""Weak symmetry on the GPU (k_se_weaksym) against the oracle restatement."""
+
+import numpy as np
+import pytest
+
+from test_oracle_stress import asym_moments, stress_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k,bc", [(2, "dirichlet"), (3, "dirichlet"), (3, "neumann_lt"),
+                                  (2, "neumann_bottom"), (3, "neumann_bottom")])
+def test_stress_matches_oracle(oracle_mod, k, bc):
+    from dolfinx_eqlb_amd import cpp
+    mesh, ft, G, f = stress_case(7, k, bc)
+    eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(mesh), k, 2, reconstruct_stress=True)
+    eq.set_boundary(ft)
+    x = eq.equilibrate_host(G, f)
+    ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f, stress=True)
+    assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max()
+    assert np.abs(asym_moments(mesh, k, x)[1]).max() < 1e-11
+    x2 = eq.equilibrate_host(G, f)
+    assert np.array_equal(x, x2)  # reproducible
+
+
+def test_stress_argument_checks():
+    from dolfinx_eqlb_amd import cpp
+    from dolfinx_eqlb_amd.mesh import create_unit_square
+    dm = cpp.DeviceMesh(create_unit_square(2))
+    with pytest.raises(RuntimeError, match="Specify all rows"):
+        cpp.SemiExplicitEquilibrator(dm, 2, 1, reconstruct_stress=True)
+    with pytest.raises(RuntimeError, match="k>1 required"):
+        cpp.SemiExplicitEquilibrator(dm, 1, 2, reconstruct_stress=True)

@@ -68,7 +68,56 @@ def tables_exact(k, deg):
                 D[n][i][1][q] = P.integrate_triangle(P.mul(P.ddy(dg.basis[i]), w))
     B = [[Fraction(comb(j, i) * (-1) ** i) for i in range(k)] for j in range(k)]
     TE, WQ = reduced_tensors(k, S, B)
-    return dict(k=k, deg=deg, nrt=nrt, nd=nd, nq=len(monos), S=S, F=F, H=H, D=D, B=B, TE=TE, WQ=WQ)
+    # weak symmetry: V[j][i][X] = int hat_j phi_i^X, and its reduction to the local H(div=0)
+    # functions per combination: VQ[ci][X][h][j] = sum_r Q[r][h] D0_r V[j][idx_r][X]
+    V = [[[P.integrate_triangle(P.mul(hat.basis[j], rt.basis[i][X])) for X in range(2)]
+          for i in range(nrt)] for j in range(3)]
+    VQ = reduced_symmetry_tensor(k, V, B)
+    return dict(k=k, deg=deg, nrt=nrt, nd=nd, nq=len(monos), S=S, F=F, H=H, D=D, B=B, TE=TE, WQ=WQ,
+                V=V, VQ=VQ)
+
+
+def _local_maps(k, B, fm, fp, rev):
+    """(idx_y, d0, Q) of a facet-pair combination: own-frame unknowns y = [mu_m | mu_p | add],
+    c = sgn * D0 y, y = ytil + Q [d | um | up | ua] (see reduced_tensors)."""
+    kb = k - 1
+    nadd = (k - 1) * (k - 2) // 2
+    ndiv = k * (k + 1) // 2 - 1
+    ny, nh = 2 * k + nadd, 1 + 2 * kb + nadd
+    zero = Fraction(0)
+    idx = [fm * k + j for j in range(k)] + [fp * k + j for j in range(k)] \
+        + [3 * k + ndiv + q for q in range(nadd)]
+    sm = 1 if ert.FACET_NORMAL_IS_OUTWARD[fm] else -1
+    sp = 1 if ert.FACET_NORMAL_IS_OUTWARD[fp] else -1
+    d0 = [sm] * k + [sp] * k + [1] * nadd
+    Q = [[zero] * nh for _ in range(ny)]
+    for j in range(k):
+        for c in range(k):
+            Q[j][c] = -(B[j][c] if rev else Fraction(int(j == c)))
+    Q[k][0] = Fraction(1)
+    for j in range(1, k):
+        Q[k + j][kb + j] = Fraction(1)
+    for q in range(nadd):
+        Q[2 * k + q][1 + 2 * kb + q] = Fraction(1)
+    return idx, d0, Q, ny, nh
+
+
+def reduced_symmetry_tensor(k, V, B):
+    zero = Fraction(0)
+    nh = 1 + 2 * (k - 1) + (k - 1) * (k - 2) // 2
+    VQ = [[[[zero] * 3 for _ in range(nh)] for _ in range(2)] for _ in range(18)]
+    for fm in range(3):
+        for fp in range(3):
+            if fm == fp:
+                continue
+            for rev in range(2):
+                ci = (fm * 3 + fp) * 2 + rev
+                idx, d0, Q, ny, nh_ = _local_maps(k, B, fm, fp, rev)
+                for X in range(2):
+                    for h in range(nh):
+                        for j in range(3):
+                            VQ[ci][X][h][j] = sum(Q[r][h] * d0[r] * V[j][idx[r]][X] for r in range(ny))
+    return VQ
 
 
 def reduced_tensors(k, S, B):
@@ -143,7 +192,7 @@ def tables_float(k, deg):
     import numpy as np
     t = tables_exact(k, deg)
     out = dict(k=k, deg=deg, nrt=t["nrt"], nd=t["nd"], nq=t["nq"])
-    for name in ("S", "F", "H", "D", "B", "TE", "WQ"):
+    for name in ("S", "F", "H", "D", "B", "TE", "WQ", "V", "VQ"):
         def shape(x):
             return (len(x),) + shape(x[0]) if isinstance(x, list) else ()
         out[name] = np.array([float(v) for v in _flat(t[name])]).reshape(shape(t[name]))
@@ -181,6 +230,8 @@ def emit(path):
         nh_ = 1 + 2 * kb_ + nadd_
         arr("TE", (18, 3, nh_ * (nh_ + 1) // 2), t["TE"])
         arr("WQ", (18, 3, nh_, 2 * k + ndiv_), t["WQ"])
+        arr("V", (3, nrt, 2), t["V"])
+        arr("VQ", (18, 2, nh_, 3), t["VQ"])
         lines.append("};")
         lines.append("")
     # Lagrange P_d (Basix numbering, equispaced): monomial coefficients and inverse mass matrix
