@@ -55,6 +55,7 @@ void dfree(T*& p)
 void free_boundary(eqlb_se* h)
 {
   dfree(h->facet_type);
+  dfree(h->bvals);
   dfree(h->node_slot);
   dfree(h->node_patch);
   dfree(h->slot_cell);
@@ -253,13 +254,15 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
   if (!h || !facet_type)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_set_boundary: null argument");
   const eqlb::DeviceMesh& m = h->mesh->m;
+  bool inhomogeneous = false;
   if (boundary_values)
   {
     const size_t nb = (size_t)h->nrhs * m.ncells * h->nrt;
-    for (size_t i = 0; i < nb; ++i)
-      if (boundary_values[i] != 0.0)
-        return fail(EQLB_ERR_UNSUPPORTED,
-                    "inhomogeneous flux boundary values are not in this build");
+    for (size_t i = 0; i < nb && !inhomogeneous; ++i)
+      inhomogeneous = (boundary_values[i] != 0.0);
+    if (inhomogeneous && h->stress)
+      return fail(EQLB_ERR_UNSUPPORTED,
+                  "inhomogeneous flux BCs with stress equilibration are not in this build");
   }
   // OrientedPatch::set_max_patch_size (se/Patch.cpp:337-404): every local node is checked
   for (int32_t i = 0; i < m.nnodes; ++i)
@@ -316,6 +319,8 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
 
   int st = 0;
   st |= upload(&h->facet_type, facet_type, (size_t)h->nrhs * m.nfacets);
+  if (inhomogeneous)
+    st |= upload(&h->bvals, boundary_values, (size_t)h->nrhs * m.ncells * h->nrt);
   st |= upload(&h->node_slot, node_slot.data(), (size_t)m.nnodes);
   st |= upload(&h->node_patch, node_patch.data(), (size_t)m.nnodes);
   st |= upload<int32_t>(&h->slot_cell, nullptr, (size_t)h->nslots);
@@ -524,6 +529,7 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
   a.tables = h->tables;
   a.flux_dg = d_g;
   a.rhs_dg = d_f;
+  a.bvals = h->bvals;
   a.out = (h->scatter == EQLB_SCATTER_SLOTS) ? h->slots : d_x;
   a.status = h->status;
   a.npatch_total = h->npatch_total;

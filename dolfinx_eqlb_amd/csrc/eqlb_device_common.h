@@ -56,9 +56,10 @@ struct Sizes
   // device table buffer: S | F | H | D | TE | WQ ; the kernel stages everything behind S in LDS
   static constexpr int NS = 3 * NRT * NRT, NF = 9 * ND * K, NHT = 3 * ND * NQ, NDT = 6 * ND * NQ;
   static constexpr int NTET = 18 * 3 * NTE, NWQT = 18 * 3 * NH * NCOL;
-  static constexpr int NTAB = NF + NHT + NDT + NTET + NWQT;
-  static constexpr int NVT = 3 * NRT * 2, NVQT = 18 * 2 * NH * 3; // weak symmetry: V, VQ (behind WQ)
-  static constexpr int OFF_TE = NS + NF + NHT + NDT, OFF_V = OFF_TE + NTET + NWQT, OFF_VQ = OFF_V + NVT;
+  static constexpr int NHB = 9 * K * K;                           // flux-BC tensor HB
+  static constexpr int NTAB = NF + NHT + NDT + NTET + NWQT + NHB;
+  static constexpr int NVT = 3 * NRT * 2, NVQT = 18 * 2 * NH * 3; // weak symmetry: V, VQ (behind HB)
+  static constexpr int OFF_TE = NS + NF + NHT + NDT, OFF_V = OFF_TE + NTET + NWQT + NHB, OFF_VQ = OFF_V + NVT;
   // workgroup size: as many waves as fit a 64 KiB LDS budget for the dense tiles (at least one)
   // per-wave staging of the gathered input rows (G, f, J of 64 cells) / the output rows
   static constexpr int FB = ((8 * ND) % 16 == 0) ? 16 : 4; // f-row piece (LDS-DMA: 16 or 4 bytes)

@@ -58,6 +58,7 @@ struct SeArgs
   const double* tables;       // S | F | H | D
   const double* flux_dg;      // [nrhs][ncells*ND*2]
   const double* rhs_dg;       // [nrhs][ncells*ND]
+  const double* bvals;        // [nrhs][ncells*NRT] global flux-boundary DOFs or nullptr (homogeneous)
   double* out;                // slots [nrhs][ncells][3][NRT] or flux_hdiv [nrhs][ncells*NRT]
   int32_t* status;            // device error flag
   int64_t npatch;             // patches of this bin
@@ -133,6 +134,7 @@ struct eqlb_se
   // device
   double* tables = nullptr;
   int8_t* facet_type = nullptr;     // [nrhs][nfacets]
+  double* bvals = nullptr;          // [nrhs][ncells*nrt] global boundary DOFs (nullptr: homogeneous)
   int64_t* node_slot = nullptr;     // [nnodes] first slot of the node's patch or -1
   int64_t* node_patch = nullptr;    // [nnodes] patch index or -1
   int32_t* node_P = nullptr;        // [nnodes] lanes per patch

@@ -31,7 +31,7 @@ size_t table_doubles(int k, int deg)
   const int nh = 1 + 2 * kb + nadd, ncol = 2 * k + ndiv;
   return (size_t)3 * nrt * nrt + (size_t)9 * nd * k + (size_t)3 * nd * nq + (size_t)6 * nd * nq
          + (size_t)18 * 3 * (nh * (nh + 1) / 2) + (size_t)18 * 3 * nh * ncol
-         + (size_t)3 * nrt * 2 + (size_t)18 * 2 * nh * 3;
+         + (size_t)9 * k * k + (size_t)3 * nrt * 2 + (size_t)18 * 2 * nh * 3;
 }
 
 template <int K, int DEG>
@@ -45,6 +45,7 @@ static void fill_tables_t(std::vector<double>& out)
   out.insert(out.end(), R::D, R::D + R::D_SIZE);
   out.insert(out.end(), R::TE, R::TE + R::TE_SIZE);
   out.insert(out.end(), R::WQ, R::WQ + R::WQ_SIZE);
+  out.insert(out.end(), R::HB, R::HB + R::HB_SIZE);
   out.insert(out.end(), R::V, R::V + R::V_SIZE);
   out.insert(out.end(), R::VQ, R::VQ + R::VQ_SIZE);
 }
@@ -90,7 +91,8 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   double* sD = sH + Z::NHT;     // [3][ND][2][NQ]
   double* sTE = sD + Z::NDT;    // [18][3][NTE]
   double* sWQ = sTE + Z::NTET;  // [18][3][NH][NCOL]
-  double* sStage = sWQ + Z::NWQT;                 // per-wave row staging
+  double* sHB = sWQ + Z::NWQT;                    // [3][3][K][K]
+  double* sStage = sHB + Z::NHB;                  // per-wave row staging
   double* sA = sStage + (BLOCK / 64) * Z::STG;    // SOLVER 0: per-group tiles
   (void)sA;
 
@@ -296,18 +298,68 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         if (sub >= off)
           t += o;
       }
+      // prescribed outward moments of sigma_a on flux-BC end facets: pf * (hat_a g DOFs) - (hat_a G)
+      // with the per-patch boundary DOFs of BoundaryData::calculate_patch_bc
+      // (base/BoundaryData.cpp:687-745) = HB[f][ln] b_facet; all |b| < 1e-7 -> skipped (:714-725)
+      double bnd_m[K], bnd_p[K];
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+      {
+        bnd_m[j] = -gm[j];
+        bnd_p[j] = -gpv[j];
+      }
+      if (a.bvals != nullptr && active && d_fixed)
+      {
+        const bool at0 = bc0 && sub == 0, atn = bcn && sub == n - 1;
+        if (at0 || atn)
+        {
+          const double* bv = a.bvals + ((int64_t)r * a.ncells + cell) * NRT;
+#pragma unroll
+          for (int side = 0; side < 2; ++side)
+          {
+            if (!(side == 0 ? at0 : atn))
+              continue;
+            const int fb = side == 0 ? fm : fp;
+            const double pfb = side == 0 ? pf_m : pf_p;
+            double bg[K];
+            bool allzero = true;
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+            {
+              bg[j] = bv[fb * K + j];
+              allzero = allzero && (fabs(bg[j]) < 1e-7);
+            }
+            if (!allzero)
+            {
+              const double* hb = sHB + (fb * 3 + ln) * K * K;
+#pragma unroll
+              for (int i = 0; i < K; ++i)
+              {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < K; ++j)
+                  s += hb[i * K + j] * bg[j];
+                if (side == 0)
+                  bnd_m[i] += pfb * s;
+                else
+                  bnd_p[i] += pfb * s;
+              }
+            }
+          }
+        }
+      }
       double delta = 0.0;
       if (d_fixed)
       {
-        const double gm0_first = shfl_d(gm[0], gbase);
-        const double gp0_last = shfl_d(gpv[0], gbase + nn - 1);
+        const double m0_first = shfl_d(bnd_m[0], gbase);
+        const double p0_last = shfl_d(bnd_p[0], gbase + nn - 1);
         const double t_last = shfl_d(t, gbase + nn - 1);
-        delta = bc0 ? gm0_first : (-gp0_last - t_last);
+        delta = bc0 ? -m0_first : (p0_last - t_last);
       }
       mu_p[0] = t + delta;
 #pragma unroll
       for (int j = 1; j < K; ++j)
-        mu_p[j] = (bcn && sub == n - 1) ? -gpv[j] : 0.0;
+        mu_p[j] = (bcn && sub == n - 1) ? bnd_p[j] : 0.0;
       double vprev[K];
 #pragma unroll
       for (int j = 0; j < K; ++j)
@@ -329,7 +381,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         mu_m[0] = -delta;
 #pragma unroll
         for (int j = 1; j < K; ++j)
-          mu_m[j] = bc0 ? -gm[j] : 0.0;
+          mu_m[j] = bc0 ? bnd_m[j] : 0.0;
       }
     }
 

@@ -40,8 +40,71 @@ def facet_types(mesh, neumann=None, nrhs=1):
     return ft
 
 
+def _neumann_facet_geometry(mesh, ft_row):
+    """(facets, cells, local facet ids, J, detJ, K) of the flux-BC facets of one RHS."""
+    facets = np.nonzero(ft_row == 2)[0]
+    cells = mesh.facet_cells[mesh.facet_cells_offsets[facets]]
+    lf = np.argmax(mesh.cell_facets[cells] == facets[:, None], axis=1)
+    J, detJ, K = cell_geometry(mesh)
+    return facets, cells, lf, J[cells], detJ[cells], K[cells]
+
+
+def boundary_dofs_from_field(mesh, k, ft_row, w):
+    """Global boundary DOFs (what BoundaryData interpolates from a FluxBC,
+    base/BoundaryData.cpp:414-623): facet DOFs D_{f,j}(w) = int_0^1 (detJ K w)(x_f(s)) . N_f s^j ds
+    of the vector field w(x, y) -> (wx, wy) on the flux-BC facets; [ncells * k(k+2)]."""
+    from .elmtlib import e_raviart_thomas as ert
+    from .elmtlib.quadrature import make_quadrature_interval
+    out = np.zeros(mesh.ncells * k * (k + 2))
+    facets, cells, lf, J, detJ, K = _neumann_facet_geometry(mesh, ft_row)
+    if facets.size == 0:
+        return out
+    s, wq = make_quadrature_interval(2 * k + 4)
+    x0 = mesh.x[mesh.cell_nodes[cells, 0], :2]
+    for f in range(3):
+        sel = np.nonzero(lf == f)[0]
+        if sel.size == 0:
+            continue
+        pts = ert.facet_points(s)[f]
+        xq = x0[sel][:, None, :] + np.einsum("cij,qj->cqi", J[sel], pts)
+        wx, wy = w(xq[..., 0], xq[..., 1])
+        wv = np.stack([wx, wy], axis=-1)
+        pb = np.einsum("cXd,cqd->cqX", K[sel], wv) * detJ[sel][:, None, None]
+        dens = pb @ np.array(ert.FACET_NORMALS[f], dtype=float)  # [c, q]
+        for j in range(k):
+            out[cells[sel] * k * (k + 2) + f * k + j] = dens @ (wq * s ** j)
+    return out
+
+
+def neumann_hat_moments(mesh, ft_row, w):
+    """r_a = int_{Gamma_N} hat_a (w . n_out) ds for all nodes (compatibility of Neumann data)."""
+    from .elmtlib import e_raviart_thomas as ert
+    from .elmtlib.quadrature import make_quadrature_interval
+    r = np.zeros(mesh.nnodes)
+    facets, cells, lf, J, detJ, K = _neumann_facet_geometry(mesh, ft_row)
+    if facets.size == 0:
+        return r
+    s, wq = make_quadrature_interval(8)
+    hat = Lagrange(1)
+    pfo = np.where(np.array(ert.FACET_NORMAL_IS_OUTWARD), 1.0, -1.0)
+    x0 = mesh.x[mesh.cell_nodes[cells, 0], :2]
+    for f in range(3):
+        sel = np.nonzero(lf == f)[0]
+        if sel.size == 0:
+            continue
+        pts = ert.facet_points(s)[f]
+        xq = x0[sel][:, None, :] + np.einsum("cij,qj->cqi", J[sel], pts)
+        wx, wy = w(xq[..., 0], xq[..., 1])
+        pb = np.einsum("cXd,cqd->cqX", K[sel], np.stack([wx, wy], axis=-1)) * detJ[sel][:, None, None]
+        dens = (pb @ np.array(ert.FACET_NORMALS[f], dtype=float)) * (np.sign(detJ[sel]) * pfo[f])[:, None]
+        hv = hat.tabulate(pts)[0]  # [q, n]
+        loc = np.einsum("cq,q,qn->cn", dens, wq, hv)
+        np.add.at(r, mesh.cell_nodes[cells[sel]].ravel(), loc.ravel())
+    return r
+
+
 def make_compatible_data(mesh, k, facet_type, degree_dg=None, seed=20241003, u_ext=None,
-                         grad_u_ext=None, f_ext=None, tol=1e-13):
+                         grad_u_ext=None, f_ext=None, tol=1e-13, neumann_flux=None):
     """Returns (flux_dg [ncells*nd*2], rhs_dg [ncells*nd]) satisfying the orthogonality.
 
     Default: smooth-plus-random data (random DG perturbation, so jumps of G are arbitrary).
@@ -84,6 +147,9 @@ def make_compatible_data(mesh, k, facet_type, degree_dg=None, seed=20241003, u_e
 
     # free nodes: not on a primal-Dirichlet facet (of RHS 0)
     ft = np.asarray(facet_type).reshape(-1, mesh.nfacets)[0]
+    if neumann_flux is not None:
+        # inhomogeneous flux BC (sigma_eq + G) . n = w . n: (f, hat_a) + (G, grad hat_a) = <w . n, hat_a>
+        r -= neumann_hat_moments(mesh, ft, neumann_flux)
     fixed = np.zeros(nnodes, dtype=bool)
     fixed[mesh.facet_nodes[ft == 1].ravel()] = True
     free = np.nonzero(~fixed)[0]

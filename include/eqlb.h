@@ -106,10 +106,12 @@ int eqlb_se_set_option(eqlb_se_t* handle, const char* key, int32_t value);
  * (base/BoundaryData.hpp: facet_type(), boundary_values(); built by
  * base/BoundaryData.cpp:279-633 from the FluxBC lists):
  *   facet_type       [nrhs][nfacets] int8, EQLB_FACET_*
- *   boundary_values  [nrhs][ncells*k(k+2)] global boundary DOFs of the flux, or NULL for
- *                    homogeneous flux BCs.  Inhomogeneous data is not in this build
- *                    (per-patch hat*g DOFs, base/BoundaryData.cpp:687-745): a non-NULL array
- *                    with a non-zero entry returns EQLB_ERR_UNSUPPORTED.
+ *   boundary_values  [nrhs][ncells*k(k+2)] GLOBAL boundary DOFs of the flux (the boundary
+ *                    functions BoundaryData fills from the FluxBC lists: facet DOFs
+ *                    int (detJ K g).N_f s^j on the flux-BC facets, zero elsewhere), or NULL for
+ *                    homogeneous flux BCs.  The per-patch values hat_a * g of
+ *                    BoundaryData::calculate_patch_bc (base/BoundaryData.cpp:687-745) are formed
+ *                    in the kernel.  Not combined with stress equilibration in this build.
  *   node_mask        [nnodes] uint8 or NULL: equilibrate only patches of nodes with mask != 0
  *                    (node ownership of a partitioned run; the reference loops
  *                    index_map(0)->size_local() owned nodes, se/reconstruction.hpp:90,286).

@@ -840,6 +840,47 @@ static void calculate_jump(const patch_t* p, const oracle_tables_t* tab, double 
   GtHat_Ea[1][1] *= hat_Tap1;
 }
 
+/* BoundaryData::calculate_patch_bc + KernelDataBC::interpolate_flux
+ * (base/BoundaryData.cpp:687-745, :171-250): DOFs on the boundary facet lfct of `cell` of
+ * hat_{hat_id} * g, g = sum_j bdofs[j] phi_{lfct,j}: evaluate at the facet interpolation points,
+ * multiply by the hat function, pull back, apply the interpolation matrix.  All DOFs smaller
+ * than 1e-7 in magnitude -> the facet is skipped (values stay zero), :714-725. */
+static void calculate_patch_bc(const oracle_tables_t* tab, const double* bglob /* [k] */, int lfct,
+                               int hat_id, const double* J, double detJ, const double* K,
+                               double* bpatch /* [k] */)
+{
+  const int k = tab->k, nqf = tab->nqf, ndofs = tab->ndofs;
+  int nzero = 0;
+  for (int i = 0; i < k; ++i)
+  {
+    bpatch[i] = 0.0;
+    if (fabs(bglob[i]) < 1e-7)
+      ++nzero;
+  }
+  if (nzero == k)
+    return;
+  for (int i = 0; i < k; ++i)
+    bpatch[i] = 0.0;
+  for (int q = 0; q < nqf; ++q)
+  {
+    const double* phi = tab->flux_basis_fct + ((size_t)(lfct * nqf + q) * ndofs + lfct * k) * 2;
+    double vr[2] = {0, 0};
+    for (int j = 0; j < k; ++j)
+    {
+      vr[0] += bglob[j] * phi[2 * j];
+      vr[1] += bglob[j] * phi[2 * j + 1];
+    }
+    /* push forward (J v / detJ), times hat, pull back (detJ K v): the maps cancel */
+    double v[2] = {(J[0] * vr[0] + J[1] * vr[1]) / detJ, (J[2] * vr[0] + J[3] * vr[1]) / detJ};
+    const double hat = tab->hat_fct[(size_t)(lfct * nqf + q) * 3 + hat_id];
+    v[0] *= hat;
+    v[1] *= hat;
+    const double m0 = detJ * (K[0] * v[0] + K[1] * v[1]), m1 = detJ * (K[2] * v[0] + K[3] * v[1]);
+    for (int i = 0; i < k; ++i)
+      bpatch[i] += MREF(tab, lfct, i, 0, q) * m0 + MREF(tab, lfct, i, 1, q) * m1;
+  }
+}
+
 /* pull-back of a flux value to the reference cell: detJ K v (se/KernelData.hpp:82-88) */
 static void pull_back_flux(double out[2], const double v[2], double detJ, const double* K)
 {
@@ -1014,17 +1055,20 @@ static int equilibrate_patch(patch_t* p, pdata_t* d, const oracle_tables_t* tab,
       for (int j = 0; j < k; ++j)
         d->cj_ta_ea[j] = 0.0;
 
-      /* flux BCs :585-638 (boundary values are per-patch values hat*g; only homogeneous
-       * data is supported by this restatement, i.e. bvals == NULL or zeros) */
+      /* flux BCs :585-638: per-patch boundary DOFs hat_a * g from the global boundary DOFs */
       if (fct_has_bc && bvals)
       {
         const int offs_bdofs = (a == 1) ? 0 : k;
+        const int lfct_b = (a == 1) ? fl_TaEam1 : fl_TaEa;
+        double bpatch[8];
+        calculate_patch_bc(tab, bvals + DM(p, 1, a, offs_bdofs), lfct_b, node_Ta, d->J + 4 * id_a,
+                           detJ, K, bpatch);
         if (a == 1)
-          c_ta_eam1 += d->prefactor[2 * id_a] * bvals[DM(p, 1, a, offs_bdofs)];
+          c_ta_eam1 += d->prefactor[2 * id_a] * bpatch[0];
         for (int j = 1; j < k; ++j)
-          COEF(p, d, r, id_a, DM(p, 0, a, offs_bdofs + j)) += bvals[DM(p, 1, a, offs_bdofs + j)];
+          COEF(p, d, r, id_a, DM(p, 0, a, offs_bdofs + j)) += bpatch[j];
         if (reversion)
-          c_t1_e0 -= d->prefactor[2 * id_a + 1] * bvals[DM(p, 1, a, offs_bdofs)];
+          c_t1_e0 -= d->prefactor[2 * id_a + 1] * bpatch[0];
       }
 
       double surfint_c_ta_eam1 = 0.0;

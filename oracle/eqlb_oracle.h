@@ -58,6 +58,7 @@ typedef struct
   const double* doftrafo;    /* [k][k] */
   const uint8_t* fct_normal_out; /* [3] */
   const int32_t* fct_dofs;   /* [3][ndf] */
+  const double* flux_basis_fct; /* [3*nqf][ndofs][2] RT basis at the facet interpolation points */
 } oracle_tables_t;
 
 /* Patch fans of nodes [node_begin, node_end) as built by OrientedPatch::initialize_patch
@@ -72,7 +73,9 @@ int oracle_build_patches(const oracle_mesh_t* mesh, int nrhs, const int8_t* face
 
 /* se::reconstruction<T,k> without stress: loops all nodes (se/reconstruction.hpp:286-313).
  *   facet_type      [nrhs][nfacets]   0 internal, 1 essnt_primal, 2 essnt_dual
- *   boundary_values [nrhs][ncells*ndofs] or NULL (homogeneous flux BCs)
+ *   boundary_values [nrhs][ncells*ndofs] GLOBAL boundary DOFs of the flux (the boundary functions of
+ *                   BoundaryData, base/BoundaryData.cpp:414-623) or NULL (homogeneous flux BCs);
+ *                   the per-patch values hat_a * g are computed as in calculate_patch_bc (:687-745)
  *   flux_dg         [nrhs][ncells*nd*2], rhs_dg [nrhs][ncells*nd]
  *   flux_hdiv       [nrhs][ncells*ndofs]  accumulated (+=) like the reference
  *   node_begin/end  sub-range of nodes (for partitioned runs); pass 0, nnodes for all.

@@ -41,7 +41,8 @@ class _Tables(C.Structure):
                 ("qpoints", C.c_void_p), ("qweights", C.c_void_p), ("flux_basis", C.c_void_p),
                 ("rhs_cell", C.c_void_p), ("rhs_fct", C.c_void_p), ("hat_cell", C.c_void_p),
                 ("hat_fct", C.c_void_p), ("M", C.c_void_p), ("doftrafo", C.c_void_p),
-                ("fct_normal_out", C.c_void_p), ("fct_dofs", C.c_void_p)]
+                ("fct_normal_out", C.c_void_p), ("fct_dofs", C.c_void_p),
+                ("flux_basis_fct", C.c_void_p)]
 
 
 def _load():
@@ -80,7 +81,7 @@ def _mesh_struct(mesh):
 
 def _tables_struct(t: Tables):
     keep = [t.qpoints, t.qweights, t.flux_basis, t.rhs_cell, t.rhs_fct, t.hat_cell, t.hat_fct,
-            t.M, t.doftrafo, t.fct_normal_out, t.fct_dofs]
+            t.M, t.doftrafo, t.fct_normal_out, t.fct_dofs, t.flux_basis_fct]
     s = _Tables(t.k, t.ndofs, t.nd, t.ndf, t.nq, t.nqf, *[_p(a) for a in keep])
     return s, keep
 

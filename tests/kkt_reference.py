@@ -32,7 +32,7 @@ def _geom(mesh, c):
     return J, detJ, np.linalg.inv(J)
 
 
-def _system(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg=None):
+def _system(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg=None, neumann_flux=None):
     """Constraint rows B, mass matrix M, right-hand side d of the patch problem."""
     degree_dg = k - 1 if degree_dg is None else degree_dg
     rt = ert.HierarchicRT(k)
@@ -107,16 +107,25 @@ def _system(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg=None):
                 row[i * ndofs:(i + 1) * ndofs] += (w * s ** j) @ dens
                 Gq = dg.tabulate(pts)[0] @ G[c]  # [q, 2]
                 pb = detJ * (Gq @ K.T)
-                densG = (pb @ nref) * sg * hat.tabulate(pts)[0][:, ln]
+                hatv = hat.tabulate(pts)[0][:, ln]
+                densG = (pb @ nref) * sg * hatv
                 val -= float(np.sum(w * s ** j * densG))
+                if fc.size == 1 and neumann_flux is not None:
+                    # prescribed total normal flux hat_a * (w . n) on the flux-BC facet
+                    x0 = mesh.x[mesh.cell_nodes[c][0], :2]
+                    xq = x0[None, :] + pts @ J.T
+                    wx, wy = neumann_flux(xq[:, 0], xq[:, 1])
+                    pbw = detJ * (np.stack([wx, wy], axis=1) @ K.T)
+                    val += float(np.sum(w * s ** j * (pbw @ nref) * sg * hatv))
             add(row, val)
 
     return np.array(rows), M, np.array(rhs), cells, n, ndofs
 
 
-def solve_patch(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg=None):
+def solve_patch(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg=None, neumann_flux=None):
     """Returns (cells, coefficients[n, ndofs]) of the constrained minimiser on the patch."""
-    B, M, d, cells, n, ndofs = _system(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg)
+    B, M, d, cells, n, ndofs = _system(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg,
+                                       neumann_flux)
     # particular solution + null space
     cp, *_ = np.linalg.lstsq(B, d, rcond=None)
     resid = np.linalg.norm(B @ cp - d)

@@ -73,8 +73,22 @@ def tables_exact(k, deg):
     V = [[[P.integrate_triangle(P.mul(hat.basis[j], rt.basis[i][X])) for X in range(2)]
           for i in range(nrt)] for j in range(3)]
     VQ = reduced_symmetry_tensor(k, V, B)
+    # per-patch flux-BC DOFs (BoundaryData::calculate_patch_bc): moments of hat_n * g on facet f from
+    # the moments b_j of g: HB[f][n][i][j] = int_0^1 p_j(s) hat_n(x_f(s)) s^i ds, int p_j s^i = delta_ij
+    hil = [[Fraction(1, i + m + 1) for m in range(k)] for i in range(k)]
+    hinv = P.solve_exact(hil, [[Fraction(int(i == j)) for j in range(k)] for i in range(k)])
+    HB = [[[[Fraction(0)] * k for _ in range(k)] for _ in range(3)] for _ in range(3)]
+    for f in range(3):
+        xs, ys = ert.FACET_PARAM[f]
+        for n in range(3):
+            hl = P.restrict_to_line(hat.basis[n], xs, ys)
+            for j in range(k):
+                pj = [hinv[j][m] for m in range(k)]  # coefficients of p_j (H symmetric)
+                prod = P._poly1d_mul(pj, hl)
+                for i in range(k):
+                    HB[f][n][i][j] = P.integrate_unit_interval(prod, i)
     return dict(k=k, deg=deg, nrt=nrt, nd=nd, nq=len(monos), S=S, F=F, H=H, D=D, B=B, TE=TE, WQ=WQ,
-                V=V, VQ=VQ)
+                V=V, VQ=VQ, HB=HB)
 
 
 def _local_maps(k, B, fm, fp, rev):
@@ -192,7 +206,7 @@ def tables_float(k, deg):
     import numpy as np
     t = tables_exact(k, deg)
     out = dict(k=k, deg=deg, nrt=t["nrt"], nd=t["nd"], nq=t["nq"])
-    for name in ("S", "F", "H", "D", "B", "TE", "WQ", "V", "VQ"):
+    for name in ("S", "F", "H", "D", "B", "TE", "WQ", "V", "VQ", "HB"):
         def shape(x):
             return (len(x),) + shape(x[0]) if isinstance(x, list) else ()
         out[name] = np.array([float(v) for v in _flat(t[name])]).reshape(shape(t[name]))
@@ -232,6 +246,7 @@ def emit(path):
         arr("WQ", (18, 3, nh_, 2 * k + ndiv_), t["WQ"])
         arr("V", (3, nrt, 2), t["V"])
         arr("VQ", (18, 2, nh_, 3), t["VQ"])
+        arr("HB", (3, 3, k, k), t["HB"])
         lines.append("};")
         lines.append("")
     # Lagrange P_d (Basix numbering, equispaced): monomial coefficients and inverse mass matrix
