@@ -1919,3 +1919,6 @@ int oracle_se_patch(const oracle_mesh_t* mesh, const oracle_tables_t* tab, int n
   patch_free(&p, &d);
   return st ? st : n;
 }
+
+/* constrained-minimisation (EV) equilibrator, shares the helpers above */
+#include "eqlb_oracle_ev.c"

@@ -108,6 +108,24 @@ int oracle_se_patch(const oracle_mesh_t* mesh, const oracle_tables_t* tab, int n
 int oracle_se_korn(const oracle_mesh_t* mesh, int nrhs, const int8_t* facet_type, double* korn,
                    int32_t node_begin, int32_t node_end);
 
+/* ev::reconstruction (ev/reconstruction.hpp:32-176, ev/solve_patch.hpp:58-238): constrained
+ * minimisation per patch in the mixed RT_k x DG_{k-1} space, dense partial-pivot LU; the flux lives
+ * in the conforming version of the hierarchic RT_k (see eqlb_oracle_ev.c for the conventions).
+ *   flux_div        [nq][k(k+2)] reference divergence of the RT basis at the cell quadrature points
+ *   cell_dofs       [ncells][k(k+2)] conforming dofmap, ndofs_glob global flux DOFs
+ *   boundary_values [nrhs][ndofs_glob] or NULL; flux_hdiv [nrhs][ndofs_glob] accumulated */
+int oracle_ev_reconstruct(const oracle_mesh_t* mesh, const oracle_tables_t* tab,
+                          const double* flux_div, int nrhs, const int8_t* facet_type,
+                          const int32_t* cell_dofs, int64_t ndofs_glob,
+                          const double* boundary_values, const double* flux_dg,
+                          const double* rhs_dg, double* flux_hdiv, int32_t node_begin,
+                          int32_t node_end);
+int oracle_ev_patch(const oracle_mesh_t* mesh, const oracle_tables_t* tab, const double* flux_div,
+                    int nrhs, const int8_t* facet_type, const int32_t* cell_dofs,
+                    int64_t ndofs_glob, const double* boundary_values, const double* flux_dg,
+                    const double* rhs_dg, int32_t node, int32_t* out_cells, double* out_u,
+                    int32_t* out_ndof_max);
+
 #ifdef __cplusplus
 }
 #endif

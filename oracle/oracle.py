@@ -19,9 +19,9 @@ _lib = None
 def build(force: bool = False):
     """Compile the C restatement (gcc) into oracle/_build/."""
     src = os.path.join(_HERE, "eqlb_oracle.c")
+    deps = [src, src[:-2] + ".h", src[:-2] + "_ev.c"]
     if force or not os.path.exists(_LIB_PATH) or \
-            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src),
-                                               os.path.getmtime(src[:-2] + ".h")):
+            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in deps):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
 
@@ -56,6 +56,8 @@ def _load():
         _lib.oracle_build_patches.restype = C.c_int
         _lib.oracle_se_korn.restype = C.c_int
         _lib.oracle_se_reconstruct_stress.restype = C.c_int
+        _lib.oracle_ev_reconstruct.restype = C.c_int
+        _lib.oracle_ev_patch.restype = C.c_int
     return _lib
 
 
@@ -183,3 +185,60 @@ def build_patches(mesh, facet_type, node_range=None):
         raise RuntimeError(f"oracle failed with status {st}")
     return dict(ncells=ncells, cells=cells, fcts=fcts, fcts_local=fl, inodes_local=il,
                 types=types, stride=stride)
+
+
+def ev_reconstruct(mesh, k, facet_type, flux_dg, rhs_dg, cell_dofs, ndofs_glob,
+                   boundary_values=None, flux_hdiv=None, node_range=None):
+    """Constrained-minimisation (EV) equilibration over all (or a range of) patches; returns
+    flux_hdiv [nrhs, ndofs_glob] in the conforming hierarchic RT_k numbering `cell_dofs`."""
+    lib = _load()
+    t, nrhs, facet_type, flux_dg, rhs_dg = _prep(mesh, k, facet_type, flux_dg, rhs_dg, None)
+    ms, keep_m = _mesh_struct(mesh)
+    ts, keep_t = _tables_struct(t)
+    cell_dofs = np.ascontiguousarray(cell_dofs, dtype=np.int32)
+    assert cell_dofs.shape == (mesh.ncells, t.ndofs)
+    if flux_hdiv is None:
+        flux_hdiv = np.zeros((nrhs, ndofs_glob))
+    assert flux_hdiv.flags.c_contiguous and flux_hdiv.shape == (nrhs, ndofs_glob)
+    if boundary_values is not None:
+        boundary_values = np.ascontiguousarray(boundary_values, dtype=np.float64)
+        assert boundary_values.shape == (nrhs, ndofs_glob)
+    nb, ne = node_range if node_range is not None else (0, mesh.nnodes)
+    st = lib.oracle_ev_reconstruct(C.byref(ms), C.byref(ts), _p(t.flux_div), C.c_int(nrhs),
+                                   _p(facet_type), _p(cell_dofs), C.c_int64(ndofs_glob),
+                                   _p(boundary_values), _p(flux_dg), _p(rhs_dg), _p(flux_hdiv),
+                                   C.c_int32(nb), C.c_int32(ne))
+    if st == -1:
+        raise RuntimeError("Patch with only one cell")
+    if st != 0:
+        raise RuntimeError(f"oracle failed with status {st}")
+    return flux_hdiv
+
+
+def ev_patch(mesh, k, facet_type, flux_dg, rhs_dg, cell_dofs, ndofs_glob, node,
+             boundary_values=None):
+    """Single EV patch: (cells, u [nrhs, N]) with N = k nf + n (k^2-k + nd) + 1 and the patch
+    numbering [facet DOFs | cell-interior flux DOFs | DG DOFs | multiplier]."""
+    lib = _load()
+    t, nrhs, facet_type, flux_dg, rhs_dg = _prep(mesh, k, facet_type, flux_dg, rhs_dg, None)
+    ms, keep_m = _mesh_struct(mesh)
+    ts, keep_t = _tables_struct(t)
+    cell_dofs = np.ascontiguousarray(cell_dofs, dtype=np.int32)
+    n = int(mesh.node_cells_offsets[node + 1] - mesh.node_cells_offsets[node])
+    nf = int(mesh.node_facets_offsets[node + 1] - mesh.node_facets_offsets[node])
+    nmax = int(np.diff(mesh.node_cells_offsets).max())
+    ndof_max = k * (nmax + 1) + nmax * (k * k - k + t.nd) + 1
+    cells = np.zeros(n, dtype=np.int32)
+    u = np.zeros((nrhs, ndof_max))
+    if boundary_values is not None:
+        boundary_values = np.ascontiguousarray(boundary_values, dtype=np.float64)
+    nm = C.c_int32(0)
+    st = lib.oracle_ev_patch(C.byref(ms), C.byref(ts), _p(t.flux_div), C.c_int(nrhs),
+                             _p(facet_type), _p(cell_dofs), C.c_int64(ndofs_glob),
+                             _p(boundary_values), _p(flux_dg), _p(rhs_dg), C.c_int32(node),
+                             _p(cells), _p(u), C.byref(nm))
+    if st < 0:
+        raise RuntimeError(f"oracle failed with status {st}")
+    assert nm.value == ndof_max
+    N = k * nf + n * (k * k - k + t.nd) + 1
+    return cells, u[:, :N]

@@ -38,6 +38,7 @@ class Tables:
     s_fct: np.ndarray
     w_fct: np.ndarray
     flux_basis_fct: np.ndarray = None  # [3*nqf][ndofs][2] RT basis at the facet points
+    flux_div: np.ndarray = None  # [nq][ndofs] reference divergence of the RT basis (EV forms)
 
 
 _cache = {}
@@ -78,6 +79,7 @@ def make_tables(k: int, degree_dg: int = None) -> Tables:
         doftrafo=np.ascontiguousarray(ert.reversal_transformation(k)),
         fct_normal_out=np.array(ert.FACET_NORMAL_IS_OUTWARD, dtype=np.uint8),
         fct_dofs=np.array(facet_closure_dofs(degree_dg), dtype=np.int32),
-        s_fct=s, w_fct=w, flux_basis_fct=np.ascontiguousarray(rt.tabulate(fpts)))
+        s_fct=s, w_fct=w, flux_basis_fct=np.ascontiguousarray(rt.tabulate(fpts)),
+        flux_div=np.ascontiguousarray(rt.tabulate_div(qp)))
     _cache[key] = t
     return t

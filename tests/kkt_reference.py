@@ -32,8 +32,13 @@ def _geom(mesh, c):
     return J, detJ, np.linalg.inv(J)
 
 
-def _system(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg=None, neumann_flux=None):
-    """Constraint rows B, mass matrix M, right-hand side d of the patch problem."""
+def _system(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg=None, neumann_flux=None,
+            ev=False):
+    """Constraint rows B, mass matrix M, right-hand side d of the patch problem.
+
+    ev=True: the constrained-minimisation (Ern-Vohralik) patch problem instead: conforming
+    sigma_a (no jump data), (div sigma_a, q) = (hat_a f + grad hat_a . G, q), and the functional
+    || sigma_a - hat_a G ||^2, whose linear term (phi_i, hat_a G) is returned as 7th entry."""
     degree_dg = k - 1 if degree_dg is None else degree_dg
     rt = ert.HierarchicRT(k)
     dg = Lagrange(degree_dg)
@@ -54,6 +59,7 @@ def _system(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg=None, neumann_
     s, w = make_quadrature_interval(2 * k + 1)
 
     M = np.zeros((n * ndofs, n * ndofs))
+    blin = np.zeros(n * ndofs)
     rows, rhs = [], []
 
     def add(row, val):
@@ -79,6 +85,11 @@ def _system(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg=None, neumann_
         fq = tabdg[0] @ f[c]
         divG = np.einsum("jd,qjd->q", G[c], gpsi)
         res = (fq - divG) * hq[:, ln]
+        if ev:
+            ghat = K.T @ np.array([[-1.0, -1.0], [1.0, 0.0], [0.0, 1.0]][ln])
+            Gq_c = tabdg[0] @ G[c]
+            res = fq * hq[:, ln] + Gq_c @ ghat
+            blin[sl] = np.einsum("q,qia,qa->i", qw * abs(detJ) * hq[:, ln], phys, Gq_c)
         for (l, m) in expo:
             mono = qp[:, 0] ** l * qp[:, 1] ** m
             row = np.zeros(n * ndofs)
@@ -109,7 +120,8 @@ def _system(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg=None, neumann_
                 pb = detJ * (Gq @ K.T)
                 hatv = hat.tabulate(pts)[0][:, ln]
                 densG = (pb @ nref) * sg * hatv
-                val -= float(np.sum(w * s ** j * densG))
+                if not ev:
+                    val -= float(np.sum(w * s ** j * densG))
                 if fc.size == 1 and neumann_flux is not None:
                     # prescribed total normal flux hat_a * (w . n) on the flux-BC facet
                     x0 = mesh.x[mesh.cell_nodes[c][0], :2]
@@ -119,7 +131,23 @@ def _system(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg=None, neumann_
                     val += float(np.sum(w * s ** j * (pbw @ nref) * sg * hatv))
             add(row, val)
 
+    if ev:
+        return np.array(rows), M, np.array(rhs), cells, n, ndofs, blin
     return np.array(rows), M, np.array(rhs), cells, n, ndofs
+
+
+def solve_patch_ev(mesh, k, node, facet_type, flux_dg, rhs_dg, neumann_flux=None):
+    """Constrained minimiser of the EV patch problem (ev/solve_patch.hpp:58-238 solves its
+    saddle-point form): (cells, broken coefficients [n, ndofs], constraint residual)."""
+    B, M, d, cells, n, ndofs, b = _system(mesh, k, node, facet_type, flux_dg, rhs_dg, None,
+                                          neumann_flux, ev=True)
+    cp, *_ = np.linalg.lstsq(B, d, rcond=None)
+    resid = np.linalg.norm(B @ cp - d)
+    N = sla.null_space(B, rcond=1e-11)
+    if N.shape[1]:
+        y = np.linalg.solve(N.T @ M @ N, N.T @ (b - M @ cp))
+        cp = cp + N @ y
+    return cells, cp.reshape(n, ndofs), resid
 
 
 def solve_patch(mesh, k, node, facet_type, flux_dg, rhs_dg, degree_dg=None, neumann_flux=None):
