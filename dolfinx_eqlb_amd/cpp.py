@@ -25,6 +25,9 @@ EXPORTED_SYMBOLS = [
     "eqlb_se_set_boundary", "eqlb_se_equilibrate", "eqlb_se_num_patches",
     "eqlb_se_export_patches", "eqlb_get_reference_table", "eqlb_se_last_kernel_ms",
     "eqlb_project_dg", "eqlb_se_equilibrate_with_kornconst",
+    "eqlb_ev_create", "eqlb_ev_destroy", "eqlb_ev_set_option", "eqlb_ev_set_dofmap",
+    "eqlb_ev_num_dofs", "eqlb_ev_set_boundary", "eqlb_ev_equilibrate", "eqlb_ev_num_patches",
+    "eqlb_ev_last_kernel_ms",
 ]
 
 _lib = None
@@ -44,7 +47,10 @@ def lib():
         L.eqlb_se_num_patches.restype = C.c_int64
         L.eqlb_se_last_kernel_ms.restype = C.c_double
         L.eqlb_mesh_max_patch_cells.restype = C.c_int32
-        for name in ("eqlb_mesh_destroy", "eqlb_se_destroy"):
+        L.eqlb_ev_num_dofs.restype = C.c_int64
+        L.eqlb_ev_num_patches.restype = C.c_int64
+        L.eqlb_ev_last_kernel_ms.restype = C.c_double
+        for name in ("eqlb_mesh_destroy", "eqlb_se_destroy", "eqlb_ev_destroy"):
             getattr(L, name).restype = None
         _lib = L
     return _lib
@@ -203,6 +209,97 @@ class SemiExplicitEquilibrator:
             self.close()
         except Exception:
             pass
+
+
+class ConstrainedMinEquilibrator:
+    """eqlb_ev_* handle: constrained-minimisation (Ern-Vohralik) equilibrator, flux in the
+    conforming hierarchic RT_k (include/eqlb.h)."""
+
+    def __init__(self, dmesh: DeviceMesh, k: int, nrhs: int, cell_dofs=None, ndofs=None):
+        self.dmesh = dmesh
+        self.k, self.nrhs = k, nrhs
+        self.nrt = k * (k + 2)
+        self.nd = k * (k + 1) // 2
+        self.output = 0
+        self._h = C.c_void_p()
+        _check(lib().eqlb_ev_create(dmesh._h, C.c_int32(k), C.c_int32(nrhs), C.byref(self._h)))
+        if cell_dofs is not None:
+            cd = np.ascontiguousarray(cell_dofs, dtype=np.int32)
+            assert cd.shape == (dmesh.mesh.ncells, self.nrt)
+            _check(lib().eqlb_ev_set_dofmap(self._h, _hp(cd), C.c_int64(int(ndofs))))
+
+    @property
+    def ndofs(self):
+        return int(lib().eqlb_ev_num_dofs(self._h))
+
+    @property
+    def num_patches(self):
+        return int(lib().eqlb_ev_num_patches(self._h))
+
+    def set_option(self, key: str, value: int):
+        _check(lib().eqlb_ev_set_option(self._h, key.encode(), C.c_int32(value)))
+        if key == "output":
+            self.output = value
+
+    def set_boundary(self, facet_type, boundary_values=None, node_mask=None):
+        m = self.dmesh.mesh
+        ft = np.ascontiguousarray(facet_type, dtype=np.int8).reshape(self.nrhs, m.nfacets)
+        bv = None
+        if boundary_values is not None:
+            bv = np.ascontiguousarray(boundary_values, dtype=np.float64)
+            assert bv.size == self.nrhs * self.ndofs
+        nm = None
+        if node_mask is not None:
+            nm = np.ascontiguousarray(node_mask, dtype=np.uint8)
+            assert nm.size == m.nnodes
+        _check(lib().eqlb_ev_set_boundary(self._h, _hp(ft), _hp(bv) if bv is not None else None,
+                                          _hp(nm) if nm is not None else None))
+
+    def _nout(self):
+        return self.dmesh.mesh.ncells * self.nrt if self.output == 1 else self.ndofs
+
+    def equilibrate_host(self, flux_dg, rhs_dg, flux_hdiv=None):
+        """Host numpy arrays in/out; flux_hdiv [nrhs, ndofs] is accumulated (+=)."""
+        m = self.dmesh.mesh
+        g = np.ascontiguousarray(flux_dg, dtype=np.float64).reshape(self.nrhs, -1)
+        f = np.ascontiguousarray(rhs_dg, dtype=np.float64).reshape(self.nrhs, -1)
+        if g.shape[1] != m.ncells * self.nd * 2 or f.shape[1] != m.ncells * self.nd:
+            raise RuntimeError("Equilibration: Input sizes does not match")
+        if flux_hdiv is None:
+            flux_hdiv = np.zeros((self.nrhs, self._nout()))
+        assert flux_hdiv.dtype == np.float64 and flux_hdiv.flags.c_contiguous
+        assert flux_hdiv.size == self.nrhs * self._nout()
+        _check(lib().eqlb_ev_equilibrate(self._h, _hp(g), _hp(f), _hp(flux_hdiv),
+                                         C.c_int32(MEM_HOST), None))
+        return flux_hdiv
+
+    def equilibrate_device(self, flux_dg_ptr: int, rhs_dg_ptr: int, flux_hdiv_ptr: int,
+                           stream: int = 0):
+        _check(lib().eqlb_ev_equilibrate(self._h, C.c_void_p(flux_dg_ptr), C.c_void_p(rhs_dg_ptr),
+                                         C.c_void_p(flux_hdiv_ptr), C.c_int32(MEM_DEVICE),
+                                         C.c_void_p(stream)))
+
+    def last_kernel_ms(self, which=0):
+        return float(lib().eqlb_ev_last_kernel_ms(self._h, C.c_int32(which)))
+
+    def close(self):
+        if self._h:
+            lib().eqlb_ev_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def reconstruct_fluxes_minimisation(flux_hdiv, flux_dg, rhs_dg, boundary_data):
+    """Stand-in for `reconstruct_fluxes_minimisation(a, l_pen, l, flux_hdiv, boundary_data)`
+    (wrappers.cpp:85-95): the forms a, l_pen, l of FluxEqlbEV.py:113-134 are fixed, their data
+    (projected flux, projected RHS) is passed as flat arrays; `boundary_data` is a configured
+    ConstrainedMinEquilibrator."""
+    return boundary_data.equilibrate_host(flux_dg, rhs_dg, flux_hdiv)
 
 
 def project_dg(dmesh: DeviceMesh, degree: int, qpoints, qweights, qvalues, bs: int = 1):

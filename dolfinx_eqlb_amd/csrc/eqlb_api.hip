@@ -479,7 +479,12 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const size_t n_g = (size_t)h->nrhs * m.ncells * h->nd * 2;
   const size_t n_f = (size_t)h->nrhs * m.ncells * h->nd;
-  const size_t n_x = (size_t)h->nrhs * m.ncells * h->nrt;
+  const size_t n_slot = (size_t)h->nrhs * m.ncells * h->nrt;
+  // EV mode writes conforming DOFs unless the broken layout is requested
+  const bool ev_conf = h->mode == 1 && h->ev_output == 0;
+  const size_t n_x = ev_conf ? (size_t)h->nrhs * h->ev_ndofs : n_slot;
+  if (h->mode == 1 && (h->scatter != EQLB_SCATTER_SLOTS || h->solver != EQLB_SOLVER_SHUFFLE))
+    return fail(EQLB_ERR_UNSUPPORTED, "EV equilibration runs with the shuffle solver and slot scatter");
 
   const double *d_g = flux_dg, *d_f = rhs_dg;
   double* d_x = flux_hdiv;
@@ -503,10 +508,10 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
 
   if (h->scatter == EQLB_SCATTER_SLOTS && !h->slots)
   {
-    if (upload<double>(&h->slots, nullptr, n_x * 3))
+    if (upload<double>(&h->slots, nullptr, n_slot * 3))
       return EQLB_ERR_DEVICE;
     // slots of (cell, vertex) pairs whose node is not equilibrated (node_mask) stay zero
-    HIP_TRY(hipMemset(h->slots, 0, n_x * 3 * sizeof(double)));
+    HIP_TRY(hipMemset(h->slots, 0, n_slot * 3 * sizeof(double)));
   }
   hipEvent_t* evs = nullptr;
   if (h->timing)
@@ -536,7 +541,7 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
   a.ncells = m.ncells;
   a.nrhs = h->nrhs;
 
-  if (h->fused && h->solver == EQLB_SOLVER_SHUFFLE)
+  if (h->mode == 1 || (h->fused && h->solver == EQLB_SOLVER_SHUFFLE))
   {
     // all bins in one launch; timing slot 0 holds the fused kernel
     eqlb::FusedBins fb{};
@@ -555,7 +560,8 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
       a.rhs = r;
       if (evs && r == 0)
         HIP_TRY(hipEventRecord(evs[0], stream));
-      const int st = eqlb::launch_se_patch_fused(h->k, h->deg, h->scatter, a, fb, stream);
+      const int st = (h->mode == 1) ? eqlb::launch_ev_patch_fused(h->k, a, fb, stream)
+                                    : eqlb::launch_se_patch_fused(h->k, h->deg, h->scatter, a, fb, stream);
       if (st)
         return fail(st, "fused patch kernel launch failed (k=%d)", h->k);
     }
@@ -604,7 +610,10 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
   {
     if (evs)
       HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS], stream));
-    eqlb::launch_reduce_slots(h->nrt, m.ncells, h->nrhs, h->slots, d_x, stream);
+    if (ev_conf)
+      eqlb::launch_ev_reduce(m, h->k, h->nrhs, h->ev_cell_dofs, h->ev_ndofs, h->slots, d_x, stream);
+    else
+      eqlb::launch_reduce_slots(h->nrt, m.ncells, h->nrhs, h->slots, d_x, stream);
     if (evs)
       HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS + 1], stream));
   }
@@ -634,7 +643,7 @@ double eqlb_se_last_kernel_ms(const eqlb_se_t* h, int32_t which)
   // (at most the last EV_RING calls).  Synchronises with the recorded events.
   if (!h || !h->ev || h->ev_calls == 0 || which < 0 || which > eqlb::MAX_BINS)
     return 0.0;
-  const bool fused_run = h->fused && h->solver == EQLB_SOLVER_SHUFFLE;
+  const bool fused_run = h->mode == 1 || (h->fused && h->solver == EQLB_SOLVER_SHUFFLE);
   if (which < eqlb::MAX_BINS && ((fused_run && which != 0) || (!fused_run && h->bins[which].npatch == 0)))
     return 0.0;
   if (which == eqlb::MAX_BINS && h->scatter != EQLB_SCATTER_SLOTS)
@@ -737,6 +746,135 @@ int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, dou
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_get_reference_table: capacity too small");
   std::copy(tab.begin() + off, tab.begin() + off + len, out);
   return (int)len;
+}
+
+// ---- constrained-minimisation (EV) equilibrator ---------------------------------------------------
+int eqlb_ev_create(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, eqlb_ev_t** handle)
+{
+  if (!handle)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_ev_create: null argument");
+  eqlb_se* se = nullptr;
+  const int st = eqlb_se_create(mesh, k, k - 1, nrhs, 0, 0, &se);
+  if (st)
+    return st;
+  se->mode = 1;
+  se->ev_ndofs = (int64_t)mesh->m.nfacets * k + (int64_t)mesh->m.ncells * (k * k - k);
+  eqlb_ev* h = new eqlb_ev();
+  h->se = se;
+  *handle = h;
+  return EQLB_OK;
+}
+
+void eqlb_ev_destroy(eqlb_ev_t* h)
+{
+  if (!h)
+    return;
+  if (h->se)
+  {
+    dfree(h->se->ev_cell_dofs);
+    eqlb_se_destroy(h->se);
+  }
+  delete h;
+}
+
+int eqlb_ev_set_option(eqlb_ev_t* h, const char* key, int32_t value)
+{
+  if (!h || !key)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_ev_set_option: null argument");
+  if (!strcmp(key, "output"))
+  {
+    if (value != 0 && value != 1)
+      return fail(EQLB_ERR_INVALID_ARGUMENT, "unknown output layout %d", value);
+    h->se->ev_output = value;
+    dfree(h->se->d_flux_hdiv); // staging size depends on the layout
+    dfree(h->se->d_flux_dg);
+    dfree(h->se->d_rhs_dg);
+    return EQLB_OK;
+  }
+  if (!strcmp(key, "timing"))
+    return eqlb_se_set_option(h->se, key, value);
+  return fail(EQLB_ERR_INVALID_ARGUMENT, "unknown option '%s'", key);
+}
+
+int eqlb_ev_set_dofmap(eqlb_ev_t* h, const int32_t* cell_dofs, int64_t ndofs)
+{
+  if (!h)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_ev_set_dofmap: null argument");
+  eqlb_se* se = h->se;
+  const eqlb::DeviceMesh& m = se->mesh->m;
+  dfree(se->ev_cell_dofs);
+  dfree(se->d_flux_hdiv);
+  dfree(se->d_flux_dg);
+  dfree(se->d_rhs_dg);
+  if (!cell_dofs)
+  {
+    se->ev_ndofs = (int64_t)m.nfacets * se->k + (int64_t)m.ncells * (se->k * se->k - se->k);
+    return EQLB_OK;
+  }
+  const size_t n = (size_t)m.ncells * se->nrt;
+  for (size_t i = 0; i < n; ++i)
+    if (cell_dofs[i] < 0 || cell_dofs[i] >= ndofs)
+      return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_ev_set_dofmap: DOF %d out of range", cell_dofs[i]);
+  if (upload(&se->ev_cell_dofs, cell_dofs, n))
+    return EQLB_ERR_DEVICE;
+  se->ev_ndofs = ndofs;
+  return EQLB_OK;
+}
+
+int64_t eqlb_ev_num_dofs(const eqlb_ev_t* h) { return h ? h->se->ev_ndofs : 0; }
+
+int eqlb_ev_set_boundary(eqlb_ev_t* h, const int8_t* facet_type, const double* boundary_values,
+                         const uint8_t* node_mask)
+{
+  if (!h)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_ev_set_boundary: null argument");
+  eqlb_se* se = h->se;
+  const int st = eqlb_se_set_boundary(se, facet_type, nullptr, node_mask);
+  if (st)
+    return st;
+  const eqlb::DeviceMesh& m = se->mesh->m;
+  bool inhomogeneous = false;
+  const size_t nb = (size_t)se->nrhs * se->ev_ndofs;
+  if (boundary_values)
+    for (size_t i = 0; i < nb && !inhomogeneous; ++i)
+      inhomogeneous = (boundary_values[i] != 0.0);
+  if (inhomogeneous)
+  {
+    // conforming boundary DOFs -> the broken per-cell layout the patch kernel reads
+    double* d_conf = nullptr;
+    if (upload(&d_conf, boundary_values, nb)
+        || upload<double>(&se->bvals, nullptr, (size_t)se->nrhs * m.ncells * se->nrt))
+    {
+      dfree(d_conf);
+      return EQLB_ERR_DEVICE;
+    }
+    hipError_t e = hipMemset(se->bvals, 0, sizeof(double) * (size_t)se->nrhs * m.ncells * se->nrt);
+    if (e == hipSuccess)
+    {
+      eqlb::launch_ev_boundary_to_broken(m, se->k, se->nrhs, se->ev_cell_dofs, se->ev_ndofs, d_conf,
+                                         se->bvals, nullptr);
+      e = hipDeviceSynchronize();
+    }
+    dfree(d_conf);
+    if (e != hipSuccess)
+      return fail(EQLB_ERR_DEVICE, "eqlb_ev_set_boundary: %s", hipGetErrorString(e));
+  }
+  return EQLB_OK;
+}
+
+int eqlb_ev_equilibrate(eqlb_ev_t* h, const double* flux_dg, const double* rhs_dg,
+                        double* flux_hdiv, int32_t memspace, void* stream)
+{
+  if (!h)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "Equilibration: Input sizes does not match");
+  return eqlb_se_equilibrate(h->se, flux_dg, rhs_dg, flux_hdiv, memspace, stream);
+}
+
+int64_t eqlb_ev_num_patches(const eqlb_ev_t* h) { return h ? h->se->npatch_total : 0; }
+
+double eqlb_ev_last_kernel_ms(const eqlb_ev_t* h, int32_t which)
+{
+  return h ? eqlb_se_last_kernel_ms(h->se, which) : 0.0;
 }
 
 } // extern "C"

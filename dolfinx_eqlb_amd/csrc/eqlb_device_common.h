@@ -60,6 +60,9 @@ struct Sizes
   static constexpr int NTAB = NF + NHT + NDT + NTET + NWQT + NHB;
   static constexpr int NVT = 3 * NRT * 2, NVQT = 18 * 2 * NH * 3; // weak symmetry: V, VQ (behind HB)
   static constexpr int OFF_TE = NS + NF + NHT + NDT, OFF_V = OFF_TE + NTET + NWQT + NHB, OFF_VQ = OFF_V + NVT;
+  // constrained-minimisation (EV) mode: HG | WG behind VQ, staged in LDS behind HB
+  static constexpr int NHG = ND * NQ, NWG = 18 * NH * ND * 2, NEV = NHG + NWG;
+  static constexpr int OFF_HG = OFF_VQ + NVQT;
   // workgroup size: as many waves as fit a 64 KiB LDS budget for the dense tiles (at least one)
   // per-wave staging of the gathered input rows (G, f, J of 64 cells) / the output rows
   static constexpr int FB = ((8 * ND) % 16 == 0) ? 16 : 4; // f-row piece (LDS-DMA: 16 or 4 bytes)
@@ -67,9 +70,10 @@ struct Sizes
   static constexpr int STG_G = 64 * ND * 2, STG_F = 64 * ND, STG_J = 64 * 4;
   static constexpr int STG_IN = STG_G + STG_F + STG_J, STG_OUT = 64 * NRT;
   static constexpr int STG = (STG_IN > STG_OUT) ? STG_IN : STG_OUT;
-  static constexpr int lds_doubles(int block, int solver)
+  static constexpr int lds_doubles(int block, int solver, int mode = 0)
   {
-    return NTAB + (block / 64) * STG + ((K > 1 && solver == 0) ? (block / P) * LDS_GROUP : 0);
+    return NTAB + (mode ? NEV : 0) + (block / 64) * STG
+           + ((K > 1 && solver == 0) ? (block / P) * LDS_GROUP : 0);
   }
   static constexpr int block_of(int solver)
   {

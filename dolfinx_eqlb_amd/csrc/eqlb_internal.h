@@ -103,6 +103,14 @@ int launch_se_patch(int k, int deg, int P, int solver, int scatter, const SeArgs
 int launch_se_patch_fused(int k, int deg, int scatter, const SeArgs& a, const FusedBins& fb,
                           hipStream_t stream);
 int launch_se_weaksym(int k, int P, const SeArgs& a, hipStream_t stream);
+int launch_ev_patch_fused(int k, const SeArgs& a, const FusedBins& fb, hipStream_t stream);
+// conforming <-> broken layout of the EV equilibrator (eqlb_ev.hip); cell_dofs may be nullptr
+// (default numbering: facet*k + j, then nfacets*k + cell*(k^2-k) + i)
+void launch_ev_boundary_to_broken(const DeviceMesh& m, int k, int nrhs, const int32_t* cell_dofs,
+                                  int64_t ndofs, const double* bv_conf, double* bv_broken,
+                                  hipStream_t stream);
+void launch_ev_reduce(const DeviceMesh& m, int k, int nrhs, const int32_t* cell_dofs, int64_t ndofs,
+                      const double* slots, double* x, hipStream_t stream);
 void launch_reduce_slots(int nrt, int32_t ncells, int32_t nrhs, const double* slots, double* x,
                          hipStream_t stream);
 int projection_matrix_host(int degree, int nq, const double* pts, const double* wts,
@@ -122,12 +130,21 @@ struct eqlb_mesh
   eqlb::DeviceMesh m;
 };
 
+struct eqlb_ev
+{
+  struct eqlb_se* se = nullptr; // patch topology, tables, slots, timing of the shared machinery
+};
+
 struct eqlb_se
 {
   eqlb_mesh* mesh = nullptr;
   int k = 0, deg = 0, nrhs = 0, stress = 0;
   int nrt = 0, nd = 0;
   int solver = EQLB_SOLVER_SHUFFLE, scatter = EQLB_SCATTER_SLOTS, timing = 0, fused = 1;
+  int mode = 0;                     // 1: constrained-minimisation (EV) patch problems
+  int ev_output = 0;                // EV: 0 conforming DOFs, 1 broken hierarchic RT_k layout
+  int32_t* ev_cell_dofs = nullptr;  // EV: device copy of the caller's dofmap or nullptr (default)
+  int64_t ev_ndofs = 0;             // EV: number of conforming flux DOFs
   bool boundary_set = false;
   int64_t npatch_total = 0, nslots = 0;
   eqlb::Bin bins[eqlb::MAX_BINS];

@@ -31,7 +31,8 @@ size_t table_doubles(int k, int deg)
   const int nh = 1 + 2 * kb + nadd, ncol = 2 * k + ndiv;
   return (size_t)3 * nrt * nrt + (size_t)9 * nd * k + (size_t)3 * nd * nq + (size_t)6 * nd * nq
          + (size_t)18 * 3 * (nh * (nh + 1) / 2) + (size_t)18 * 3 * nh * ncol
-         + (size_t)9 * k * k + (size_t)3 * nrt * 2 + (size_t)18 * 2 * nh * 3;
+         + (size_t)9 * k * k + (size_t)3 * nrt * 2 + (size_t)18 * 2 * nh * 3
+         + (size_t)nd * nq + (size_t)18 * nh * nd * 2;
 }
 
 template <int K, int DEG>
@@ -48,6 +49,8 @@ static void fill_tables_t(std::vector<double>& out)
   out.insert(out.end(), R::HB, R::HB + R::HB_SIZE);
   out.insert(out.end(), R::V, R::V + R::V_SIZE);
   out.insert(out.end(), R::VQ, R::VQ + R::VQ_SIZE);
+  out.insert(out.end(), R::HG, R::HG + R::HG_SIZE);
+  out.insert(out.end(), R::WG, R::WG + R::WG_SIZE);
 }
 
 int fill_tables_host(int k, int deg, std::vector<double>& out)
@@ -79,7 +82,13 @@ int fill_tables_host(int k, int deg, std::vector<double>& out)
 #endif
 
 // ---- the patch kernel ---------------------------------------------------------------------------
-template <int K, int DEG, int P, int SOLVER, int SCATTER, int BLOCK>
+// MODE 0: semi-explicit equilibration.  MODE 1: the constrained-minimisation patch problem of
+// ev/solve_patch.hpp:58-238 (mixed RT_k x DG_{k-1} saddle point, (ndof+1)^2 LU per patch in the
+// reference) solved in the SAME reduced unknowns: the divergence constraint fixes the div-moment
+// DOFs and the zero-order facet moments explicitly (conforming particular solution: no jump data),
+// what remains is the SPD minimisation of || sigma - hat_a G || over the patch-wise H(div=0) space,
+// i.e. the same matrix with the additional load (phi_h, hat_a G) (tensors HG, WG).
+template <int K, int DEG, int P, int SOLVER, int SCATTER, int BLOCK, int MODE = 0>
 __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t block_id, double* lds)
 {
   using Z = Sizes<K, DEG, P>;
@@ -92,13 +101,19 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   double* sTE = sD + Z::NDT;    // [18][3][NTE]
   double* sWQ = sTE + Z::NTET;  // [18][3][NH][NCOL]
   double* sHB = sWQ + Z::NWQT;                    // [3][3][K][K]
-  double* sStage = sHB + Z::NHB;                  // per-wave row staging
+  double* sHG = sHB + Z::NHB;                     // MODE 1: [ND][NQ]
+  double* sWG = sHG + Z::NHG;                     // MODE 1: [18][NH][ND][2]
+  double* sStage = sHB + Z::NHB + (MODE ? Z::NEV : 0); // per-wave row staging
+  (void)sWG;
   double* sA = sStage + (BLOCK / 64) * Z::STG;    // SOLVER 0: per-group tiles
   (void)sA;
 
   const int tid = threadIdx.x;
   for (int i = tid; i < Z::NTAB; i += BLOCK)
     lds[i] = a.tables[Z::NS + i];
+  if constexpr (MODE == 1)
+    for (int i = tid; i < Z::NEV; i += BLOCK)
+      sHG[i] = a.tables[Z::OFF_HG + i];
   __syncthreads();
 
   const int lane = tid & 63;
@@ -211,6 +226,8 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
     // full[] collects the particular solution in the load-tensor column order
     // [mu_m (K) | mu_p (K) | sgn * c_div (NDIV)]
     double gm[K], gpv[K], Rq[NQ];
+    double LeG[MODE ? NH : 1]; // MODE 1: (phi_h, hat_a G)
+    (void)LeG;
     {
       // adj[X][d] = detJ * K[X][d];  nu_f = adj^T N_f, N = {(-1,-1), (-1,0), (0,1)}
       const double a00 = J11, a01 = -J01, a10 = -J10, a11 = J00;
@@ -224,7 +241,38 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
         Rq[q] = 0.0;
-      if (active)
+      if constexpr (MODE == 1)
+      {
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+          LeG[h] = 0.0;
+        if (active)
+        {
+          const double2* gp_ = reinterpret_cast<const double2*>(a.flux_dg + ((int64_t)r * a.ncells + cell) * (ND * 2));
+          const double* fp_ = a.rhs_dg + ((int64_t)r * a.ncells + cell) * ND;
+          const double* tH = sH + ln * ND * NQ;
+          const double* wg = sWG + ci * NH * ND * 2;
+          // reference gradient of the hat function of the patch node
+          const double dh0 = (ln == 0) ? -1.0 : ((ln == 1) ? 1.0 : 0.0);
+          const double dh1 = (ln == 0) ? -1.0 : ((ln == 2) ? 1.0 : 0.0);
+#pragma unroll
+          for (int i = 0; i < ND; ++i)
+          {
+            const double2 g2 = gp_[i];
+            const double fd = detJ * fp_[i];
+            // detJ * grad hat . G_i = grad_ref hat . (adj G_i)
+            const double gg = dh0 * (a00 * g2.x + a01 * g2.y) + dh1 * (a10 * g2.x + a11 * g2.y);
+            const double jt0 = J00 * g2.x + J10 * g2.y, jt1 = J01 * g2.x + J11 * g2.y; // J^T G_i
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+              Rq[q] += fd * tH[i * NQ + q] + gg * sHG[i * NQ + q];
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+              LeG[h] += wg[(h * ND + i) * 2] * jt0 + wg[(h * ND + i) * 2 + 1] * jt1;
+          }
+        }
+      }
+      else if (active)
       {
         const double2* gp_ = EQLB_STAGE_IN
                                  ? reinterpret_cast<const double2*>(stgG + lane * (ND * 2))
@@ -426,6 +474,8 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
           s2 += wq[(2 * NH + h) * NCOL + c] * full[c];
         }
         Le[h] = -(g0 * s0 + g1 * s1 + g2 * s2);
+        if constexpr (MODE == 1)
+          Le[h] += LeG[h];
       }
     }
 
@@ -1099,6 +1149,64 @@ __global__ void __launch_bounds__(256, (K <= 2 ? EQLB_FUSED_WAVES : 1)) k_se_pat
     se_patch_body<K, DEG, 64, SOLVER, SCATTER, 256>(a, lb, lds);
     break;
   }
+}
+
+// constrained-minimisation (EV) patch problems, all bins in one launch (MODE 1 of the body)
+template <int K, int DEG>
+__global__ void __launch_bounds__(256, (K <= 2 ? 2 : 1)) k_ev_patch_fused(const SeArgs a0, const FusedBins fb)
+{
+  extern __shared__ double lds[];
+  const int64_t bid = blockIdx.x;
+  int b = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_BINS; ++i)
+    if (bid >= fb.block_start[i])
+      b = i;
+  SeArgs a = a0;
+  a.npatch = fb.npatch[b];
+  a.slot_offset = fb.slot_offset[b];
+  a.patch_offset = fb.patch_offset[b];
+  const int64_t lb = bid - fb.block_start[b];
+  switch (b)
+  {
+  case 0:
+    se_patch_body<K, DEG, 4, 1, 0, 256, 1>(a, lb, lds);
+    break;
+  case 1:
+    se_patch_body<K, DEG, 8, 1, 0, 256, 1>(a, lb, lds);
+    break;
+  case 2:
+    se_patch_body<K, DEG, 16, 1, 0, 256, 1>(a, lb, lds);
+    break;
+  case 3:
+    se_patch_body<K, DEG, 32, 1, 0, 256, 1>(a, lb, lds);
+    break;
+  default:
+    se_patch_body<K, DEG, 64, 1, 0, 256, 1>(a, lb, lds);
+    break;
+  }
+}
+
+template <int K, int DEG>
+static int launch_ev_fused_kd(const SeArgs& a, const FusedBins& fb, hipStream_t stream)
+{
+  const size_t lds_bytes = sizeof(double) * (size_t)Sizes<K, DEG, 8>::lds_doubles(256, 1, 1);
+  const int64_t grid = fb.block_start[MAX_BINS];
+  if (grid == 0)
+    return 0;
+  hipLaunchKernelGGL((k_ev_patch_fused<K, DEG>), dim3((unsigned)grid), dim3(256), lds_bytes, stream, a, fb);
+  return (hipGetLastError() == hipSuccess) ? 0 : EQLB_ERR_DEVICE;
+}
+
+int launch_ev_patch_fused(int k, const SeArgs& a, const FusedBins& fb, hipStream_t stream)
+{
+  if (k == 1)
+    return launch_ev_fused_kd<1, 0>(a, fb, stream);
+  if (k == 2)
+    return launch_ev_fused_kd<2, 1>(a, fb, stream);
+  if (k == 3)
+    return launch_ev_fused_kd<3, 2>(a, fb, stream);
+  return EQLB_ERR_UNSUPPORTED;
 }
 
 // flux_hdiv[r][cell][i] += slot0 + slot1 + slot2  (fixed order -> bitwise reproducible)

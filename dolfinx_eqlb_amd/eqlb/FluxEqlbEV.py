@@ -1,0 +1,81 @@
+"""Flux equilibration by patch-wise constrained minimisation (Ern & Vohralik) - host-side mirror
+of the reference's `FluxEqlbEV` (python/dolfinx_eqlb/eqlb/FluxEqlbEV.py:20-188) on flat arrays.
+
+Same constructor arguments, methods and error behaviour.  The UFL forms the reference builds
+(FluxEqlbEV.py:113-134) are fixed, so only their data is kept; the reconstructed flux lives in the
+conforming hierarchic RT_k (dolfinx_eqlb_amd/eqlb/conforming.py) instead of the Basix RT_k space.
+All numerical work happens in libeqlb_amd.so on the GPU.
+"""
+
+import typing
+
+import numpy as np
+
+from .. import cpp
+from ..mesh import Mesh
+from .conforming import broken_to_conforming, conforming_dofmap
+from .FluxEqlbSE import fluxbc
+
+
+class FluxEqlbEV:
+    """Equilibrate fluxes by a series of constrained minimisation problems."""
+
+    def __init__(self, degree_flux: int, msh: Mesh, list_rhs: typing.List[np.ndarray],
+                 list_proj_flux: typing.List[np.ndarray],
+                 device_mesh: typing.Optional[cpp.DeviceMesh] = None):
+        self.degree_flux = degree_flux
+        self.n_fluxes = len(list_rhs)
+        self.equilibrate_stresses = False  # FluxEqlbEV.py:43
+        if len(list_proj_flux) != self.n_fluxes:
+            raise RuntimeError("Missmatching inputs!")  # FluxEqlbEV.py:69-70
+        self.mesh = msh
+        self.list_rhs = [np.ascontiguousarray(r, dtype=np.float64).ravel() for r in list_rhs]
+        self.list_proj_flux = [np.ascontiguousarray(g, dtype=np.float64).ravel()
+                               for g in list_proj_flux]
+        nd = degree_flux * (degree_flux + 1) // 2
+        if any(r.size != nd * msh.ncells for r in self.list_rhs) or \
+                any(g.size != 2 * nd * msh.ncells for g in self.list_proj_flux):
+            raise RuntimeError("Equilibration: Input sizes does not match")
+        self.device_mesh = device_mesh if device_mesh is not None else cpp.DeviceMesh(msh)
+        # V_flux: conforming RT_k (FluxEqlbEV.py:100)
+        self.cell_dofs, self.ndofs = conforming_dofmap(msh, degree_flux)
+        self._eq = cpp.ConstrainedMinEquilibrator(self.device_mesh, degree_flux, self.n_fluxes)
+        self.list_flux = np.zeros((self.n_fluxes, self.ndofs))
+        self.boundary_data = None
+
+    def set_boundary_conditions(self, list_bfct_prime: typing.List[np.ndarray],
+                                list_bcs_flux: typing.List[typing.List[fluxbc]]):
+        """FluxEqlbEV.py:136-165."""
+        if self.n_fluxes != len(list_bfct_prime) or self.n_fluxes != len(list_bcs_flux):
+            raise RuntimeError("Mismatching inputs!")
+        from ..synthetic import boundary_dofs_from_field
+        k = self.degree_flux
+        ft = np.zeros((self.n_fluxes, self.mesh.nfacets), dtype=np.int8)
+        bv = None
+        for i in range(self.n_fluxes):
+            ft[i, np.asarray(list_bfct_prime[i], dtype=np.int64)] = 1
+            for bc in list_bcs_flux[i]:
+                ft[i, bc.facets] = 2
+            for bc in list_bcs_flux[i]:
+                if bc.value is not None:
+                    if bv is None:
+                        bv = np.zeros_like(self.list_flux)
+                    row = np.zeros(self.mesh.nfacets, dtype=np.int8)
+                    row[bc.facets] = 2
+                    bv[i] += broken_to_conforming(
+                        self.mesh, k, boundary_dofs_from_field(self.mesh, k, row, bc.value))
+        self.facet_type = ft
+        self.boundary_values = bv
+        self._eq.set_boundary(ft, boundary_values=bv)
+        self.boundary_data = self._eq
+
+    def equilibrate_fluxes(self):
+        """Equilibrate the fluxes (accumulates into list_flux, FluxEqlbEV.py:167-176)."""
+        if self.boundary_data is None:
+            raise RuntimeError("Boundary conditions have not been set")
+        cpp.reconstruct_fluxes_minimisation(self.list_flux, np.stack(self.list_proj_flux),
+                                            np.stack(self.list_rhs), self.boundary_data)
+
+    def get_reconstructed_fluxes(self, subproblem: int):
+        """The reconstructed flux (conforming RT_k DOFs), FluxEqlbEV.py:178-188."""
+        return self.list_flux[subproblem]

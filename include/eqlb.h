@@ -202,6 +202,55 @@ int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, dou
  * 0 if nothing was recorded.  Setting the option again resets the ring. */
 double eqlb_se_last_kernel_ms(const eqlb_se_t* handle, int32_t which);
 
+/* ---------------------------------------------------------------------------------------------
+ * Constrained-minimisation equilibrator (Ern & Vohralik) - replaces
+ * `reconstruct_fluxes_minimisation(a, l_pen, l, flux_hdiv, boundary_data)`
+ * (python/dolfinx_eqlb/wrappers.cpp:85-95 -> ev/reconstruction.hpp:32-176,
+ * ev/solve_patch.hpp:58-238) behind `FluxEqlbEV.equilibrate_fluxes` (eqlb/FluxEqlbEV.py:167-176).
+ *
+ * The forms of FluxEqlbEV.py:113-134 are fixed (a = (sig,v) - (r,div v) + (div sig,q),
+ * l = hat G.v + (hat f + grad hat . G) q with G = list_proj_flux, f = list_rhs), so the UFL/FFCx
+ * form objects of the reference signature are replaced by the flat arrays G, f.  Each patch
+ * problem has the unique solution of the reference's (ndof+1)^2 saddle-point LU; it is computed in
+ * the reduced unknowns of the semi-explicit kernel.
+ *
+ * Output space: H(div)-conforming RT_k.  Without Basix the conforming version of the hierarchic
+ * RT_k of create_hierarchic_rt is used: k facet DOFs per facet in the global facet frame (parameter
+ * from the lower to the higher node id, normal n_E = (t_y, -t_x), t = x_hi - x_lo), then k^2-k
+ * interior DOFs per cell.  Default numbering: facet*k + j, then nfacets*k + cell*(k^2-k) + i;
+ * `eqlb_ev_set_dofmap` installs the caller's cell->dof table instead (the conforming dofmap
+ * `V_flux.dofmap.list` of ev/Patch.cpp:497-501, local order of the hierarchic element).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct eqlb_ev eqlb_ev_t;
+
+int eqlb_ev_create(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, eqlb_ev_t** handle);
+void eqlb_ev_destroy(eqlb_ev_t* handle);
+
+/* "output": 0 conforming DOFs (default), 1 broken hierarchic RT_k layout [ncells*k(k+2)] as
+ * eqlb_se_equilibrate writes it; "timing": as eqlb_se_set_option. */
+int eqlb_ev_set_option(eqlb_ev_t* handle, const char* key, int32_t value);
+
+/* cell_dofs [ncells][k(k+2)] host array (NULL restores the default numbering), ndofs = size of the
+ * conforming space.  Call before eqlb_ev_set_boundary. */
+int eqlb_ev_set_dofmap(eqlb_ev_t* handle, const int32_t* cell_dofs, int64_t ndofs);
+int64_t eqlb_ev_num_dofs(const eqlb_ev_t* handle);
+
+/* facet_type as eqlb_se_set_boundary; boundary_values [nrhs][ndofs] conforming boundary DOFs
+ * (facet DOFs of the prescribed normal flux on the flux-BC facets, zero elsewhere) or NULL; the
+ * per-patch values hat_a * g (base/BoundaryData.cpp:687-745) are formed in the kernel.
+ * node_mask as eqlb_se_set_boundary. */
+int eqlb_ev_set_boundary(eqlb_ev_t* handle, const int8_t* facet_type,
+                         const double* boundary_values, const uint8_t* node_mask);
+
+/* flux_dg [nrhs][ncells*k(k+1)], rhs_dg [nrhs][ncells*k(k+1)/2] as eqlb_se_equilibrate;
+ * flux_hdiv [nrhs][ndofs] (or [nrhs][ncells*k(k+2)] with "output" = 1) is ACCUMULATED (+=),
+ * ev/solve_patch.hpp:223-227. */
+int eqlb_ev_equilibrate(eqlb_ev_t* handle, const double* flux_dg, const double* rhs_dg,
+                        double* flux_hdiv, int32_t memspace, void* stream);
+int64_t eqlb_ev_num_patches(const eqlb_ev_t* handle);
+/* which = 0: patch kernel (all bins in one launch), 5: reduction to the conforming DOFs */
+double eqlb_ev_last_kernel_ms(const eqlb_ev_t* handle, int32_t which);
+
 #ifdef __cplusplus
 }
 #endif

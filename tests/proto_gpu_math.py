@@ -21,8 +21,12 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from gen_tables import tables_float  # noqa: E402
 
 
-def patch_solve(mesh, tab, fan, node_idx, facet_type_r, G, f):
-    """One patch, one RHS. fan: dict from oracle.build_patches; returns (cells, coeffs[n, nrt])."""
+def patch_solve(mesh, tab, fan, node_idx, facet_type_r, G, f, ev=False, bvals=None):
+    """One patch, one RHS. fan: dict from oracle.build_patches; returns (cells, coeffs[n, nrt]).
+
+    ev=True: the constrained-minimisation (EV) patch problem in the same reduced unknowns: no jump
+    data (conforming particular solution), divergence data hat f + grad hat . G and the extra load
+    (phi_h, hat G); bvals [ncells, nrt]: broken-layout boundary DOFs of the flux BC (EV only)."""
     k, nrt, nd, nq = tab["k"], tab["nrt"], tab["nd"], tab["nq"]
     kb = k - 1
     nadd = (k - 1) * (k - 2) // 2
@@ -67,6 +71,14 @@ def patch_solve(mesh, tab, fan, node_idx, facet_type_r, G, f):
         gp = pf_p * np.einsum("ij,i->j", F[fp, ln], Gc @ nu_p)
         Ghat = Gc @ adj.T  # [nd, X] = (adj G_i)_X
         R = detJ * (fc @ H[ln]) - np.einsum("iX,iXq->q", Ghat, D[ln])
+        blin = None
+        if ev:
+            gm = np.zeros(k)
+            gp = np.zeros(k)
+            ghat_ref = np.array([[-1.0, -1.0], [1.0, 0.0], [0.0, 1.0]])[ln]
+            R = detJ * (fc @ H[ln]) + (Ghat @ ghat_ref) @ tab["HG"]
+            JtG = Gc @ J  # [nd, c] = (J^T G_d)_c
+            blin = sgn * np.einsum("idc,dc->i", tab["WGF"][ln], JtG)
         R0 = sgn * R[0]
         # active DOF indices: [minus facet k | plus facet k | add | div]
         idx = [fm * k + j for j in range(k)] + [fp * k + j for j in range(k)] \
@@ -75,8 +87,14 @@ def patch_solve(mesh, tab, fan, node_idx, facet_type_r, G, f):
         Mact = (g[0, 0] * S[0] + g[0, 1] * S[1] + g[1, 1] * S[2])[np.ix_(idx, idx)] / abs(detJ)
         sg = np.array([pf_m] * k + [pf_p] * k + [1.0] * (nadd + ndiv))
         My = Mact * sg[:, None] * sg[None, :]
+        bm = bp = np.zeros(k)
+        if ev and bvals is not None:
+            # prescribed outward moments pf * HB b of hat_a * g on the end facets
+            bm = pf_m * tab["HB"][fm, ln] @ bvals[c, fm * k:(fm + 1) * k]
+            bp = pf_p * tab["HB"][fp, ln] @ bvals[c, fp * k:(fp + 1) * k]
         lanes.append(dict(c=c, fm=fm, fp=fp, ln=ln, pf_m=pf_m, pf_p=pf_p, rev_m=rev_m,
-                          rev_p=rev_p, gm=gm, gp=gp, R=R, R0=R0, My=My, idx=idx))
+                          rev_p=rev_p, gm=gm - bm, gp=gp - bp, R=R, R0=R0, My=My, idx=idx,
+                          blin=blin, sg=sg))
 
     # jumps on the plus facets (owner frame), zero-order chain
     for i, L in enumerate(lanes):
@@ -141,6 +159,8 @@ def patch_solve(mesh, tab, fan, node_idx, facet_type_r, G, f):
             Q[2 * k + q, 1 + 2 * kb + q] = 1.0
         Te = Q.T @ L["My"][:ny, :ny] @ Q
         Le = -Q.T @ w[:ny]
+        if ev:
+            Le += Q.T @ (L["sg"] * L["blin"][L["idx"]])[:ny]
         fi_m = i
         fi_p = (i + 1) % nf if interior else i + 1
         gidx = [0] + [1 + fi_m * kb + j for j in range(kb)] + [1 + fi_p * kb + j for j in range(kb)] \
@@ -177,7 +197,7 @@ def patch_solve(mesh, tab, fan, node_idx, facet_type_r, G, f):
     return cells[1:n + 1], out
 
 
-def reconstruct(mesh, k, deg, facet_type, flux_dg, rhs_dg, fans):
+def reconstruct(mesh, k, deg, facet_type, flux_dg, rhs_dg, fans, ev=False, bvals=None):
     tab = tables_float(k, deg)
     nd, nrt = tab["nd"], tab["nrt"]
     G = flux_dg.reshape(mesh.ncells, nd, 2)
@@ -185,6 +205,7 @@ def reconstruct(mesh, k, deg, facet_type, flux_dg, rhs_dg, fans):
     ft = np.asarray(facet_type).reshape(-1, mesh.nfacets)[0]
     x = np.zeros((mesh.ncells, nrt))
     for node in range(mesh.nnodes):
-        cells, coef = patch_solve(mesh, tab, fans, node, ft, G, f)
+        cells, coef = patch_solve(mesh, tab, fans, node, ft, G, f, ev=ev,
+                                  bvals=None if bvals is None else bvals.reshape(mesh.ncells, nrt))
         np.add.at(x, cells, coef)
     return x.reshape(-1)

@@ -1,0 +1,114 @@
+"""HIP constrained-minimisation (EV) equilibrator through the C ABI against the saddle-point LU
+oracle.  Tolerance: 1e-11 relative to the largest DOF (fp64)."""
+
+import numpy as np
+import pytest
+
+from cases import BCS, make_case
+from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
+from dolfinx_eqlb_amd.eqlb.conforming import (broken_to_conforming, conforming_dofmap,
+                                              conforming_to_broken)
+from dolfinx_eqlb_amd.mesh import create_unit_square
+from dolfinx_eqlb_amd.synthetic import boundary_dofs_from_field, facet_types, make_compatible_data
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-11
+
+
+def _close(x, ref):
+    return np.abs(x - ref).max() <= RTOL * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+@pytest.mark.parametrize("bc", ["dirichlet", "neumann_lt", "neumann_bottom"])
+@pytest.mark.parametrize("shuffle", [77, None])
+def test_ev_matches_oracle(oracle_mod, k, bc, shuffle):
+    from dolfinx_eqlb_amd import cpp
+    mesh, ft, G, f = make_case(6, k, bc, shuffle=shuffle)
+    cd, nd = conforming_dofmap(mesh, k)
+    ref = oracle_mod.ev_reconstruct(mesh, k, ft, G, f, cd, nd)
+    eq = cpp.ConstrainedMinEquilibrator(cpp.DeviceMesh(mesh), k, 1)
+    assert eq.ndofs == nd
+    eq.set_boundary(ft)
+    x = eq.equilibrate_host(G, f)
+    assert _close(x, ref)
+    # accumulation semantics
+    x2 = eq.equilibrate_host(G, f, x.copy())
+    assert _close(x2, 2 * ref)
+    # broken output: both sides of every facet carry the same normal trace, div sigma = Pi f
+    eq.set_option("output", 1)
+    xb = eq.equilibrate_host(G, f)[0]
+    assert _close(xb, conforming_to_broken(mesh, k, ref[0]))
+    zG = np.zeros_like(G[0])
+    assert chk.check_jump_condition(mesh, k, xb, zG, atol=1e-10)
+    res, nrm = chk.divergence_residual(mesh, k, xb, zG, f[0])
+    assert res < 1e-10 * nrm
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_ev_inhomogeneous_bc_and_dofmap(oracle_mod, k):
+    from dolfinx_eqlb_amd import cpp
+
+    def w(x, y):
+        return (0 * x + 0.8, 0 * x - 0.6) if k == 1 else (1.0 + 0.5 * x - 0.3 * y,
+                                                           -0.7 + 0.2 * x + 0.4 * y)
+    mesh = create_unit_square(7, shuffle_seed=5, perturb=0.3)
+    ft = facet_types(mesh, BCS["neumann_lt"])
+    G, f = make_compatible_data(mesh, k, ft, neumann_flux=w)
+    cd, nd = conforming_dofmap(mesh, k)
+    # a caller-supplied numbering: random permutation of the default one
+    perm = np.random.default_rng(3).permutation(nd).astype(np.int32)
+    cdp = perm[cd]
+    bv = broken_to_conforming(mesh, k, boundary_dofs_from_field(mesh, k, ft[0], w))
+    ref = oracle_mod.ev_reconstruct(mesh, k, ft, G[None], f[None], cd, nd,
+                                    boundary_values=bv[None])[0]
+    dm = cpp.DeviceMesh(mesh)
+    eq = cpp.ConstrainedMinEquilibrator(dm, k, 1)
+    eq.set_boundary(ft, boundary_values=bv)
+    x = eq.equilibrate_host(G[None], f[None])[0]
+    assert _close(x, ref)
+    sel = np.nonzero(bv != 0)[0]
+    assert sel.size and np.allclose(x[sel], bv[sel], atol=1e-10)
+    eqp = cpp.ConstrainedMinEquilibrator(dm, k, 1, cell_dofs=cdp, ndofs=nd)
+    bvp = np.zeros(nd)
+    bvp[perm] = bv
+    eqp.set_boundary(ft, boundary_values=bvp)
+    xp = eqp.equilibrate_host(G[None], f[None])[0]
+    assert _close(xp[perm], ref)
+
+
+def test_ev_multirhs(oracle_mod):
+    from dolfinx_eqlb_amd import cpp
+    k = 2
+    mesh = create_unit_square(6, shuffle_seed=2, perturb=0.2)
+    ft = np.concatenate([facet_types(mesh, BCS["dirichlet"]), facet_types(mesh, BCS["neumann_lt"]),
+                         facet_types(mesh, BCS["neumann_bottom"])])
+    data = [make_compatible_data(mesh, k, ft[i:i + 1], seed=100 + i) for i in range(3)]
+    G = np.stack([d[0] for d in data])
+    f = np.stack([d[1] for d in data])
+    cd, nd = conforming_dofmap(mesh, k)
+    ref = oracle_mod.ev_reconstruct(mesh, k, ft, G, f, cd, nd)
+    eq = cpp.ConstrainedMinEquilibrator(cpp.DeviceMesh(mesh), k, 3)
+    eq.set_boundary(ft)
+    assert _close(eq.equilibrate_host(G, f), ref)
+
+
+def test_flux_eqlb_ev_class(oracle_mod):
+    """The FluxEqlbEV mirror: convergence-independent sanity = oracle on the same arrays."""
+    from dolfinx_eqlb_amd.eqlb.FluxEqlbEV import FluxEqlbEV
+    from dolfinx_eqlb_amd.eqlb.FluxEqlbSE import fluxbc
+    k = 2
+    mesh, ft, G, f = make_case(5, k, "neumann_bottom")
+    bf = mesh.boundary_facets()
+    prime = bf[ft[0][bf] == 1]
+    dual = bf[ft[0][bf] == 2]
+    eq = FluxEqlbEV(k, mesh, [f[0]], [G[0]])
+    with pytest.raises(RuntimeError):
+        eq.equilibrate_fluxes()
+    eq.set_boundary_conditions([prime], [[fluxbc(0, dual)]])
+    eq.equilibrate_fluxes()
+    cd, nd = conforming_dofmap(mesh, k)
+    ref = oracle_mod.ev_reconstruct(mesh, k, ft, G, f, cd, nd)[0]
+    assert _close(eq.get_reconstructed_fluxes(0), ref)
+    with pytest.raises(RuntimeError):
+        FluxEqlbEV(k, mesh, [f[0]], [G[0], G[0]])

@@ -87,8 +87,30 @@ def tables_exact(k, deg):
                 prod = P._poly1d_mul(pj, hl)
                 for i in range(k):
                     HB[f][n][i][j] = P.integrate_unit_interval(prod, i)
+    # constrained-minimisation (EV) equilibrator: HG[i][q] = int psi_i mono_q (moments of
+    # grad hat . G), WGF[n][i][d][c] = int hat_n psi_d phi_i^c (linear term (phi_i, hat_n G)) and its
+    # reduction WG[ci][h][d][c] = sum_r Q[r][h] D0_r WGF[ln][idx_r][d][c], ln = 3 - fm - fp
+    HG = [[P.integrate_triangle(P.mul(dg.basis[i], P.monomial(l, m))) for (l, m) in monos]
+          for i in range(nd)]
+    WGF = [[[[P.integrate_triangle(P.mul(P.mul(hat.basis[n], dg.basis[d]), rt.basis[i][c]))
+              for c in range(2)] for d in range(nd)] for i in range(nrt)] for n in range(3)]
+    nh = 1 + 2 * (k - 1) + (k - 1) * (k - 2) // 2
+    WG = [[[[Fraction(0)] * 2 for _ in range(nd)] for _ in range(nh)] for _ in range(18)]
+    for fm in range(3):
+        for fp in range(3):
+            if fm == fp:
+                continue
+            ln = 3 - fm - fp
+            for rev in range(2):
+                ci = (fm * 3 + fp) * 2 + rev
+                idx, d0, Q, ny, nh_ = _local_maps(k, B, fm, fp, rev)
+                for h in range(nh):
+                    for d in range(nd):
+                        for c in range(2):
+                            WG[ci][h][d][c] = sum(Q[r][h] * d0[r] * WGF[ln][idx[r]][d][c]
+                                                  for r in range(ny))
     return dict(k=k, deg=deg, nrt=nrt, nd=nd, nq=len(monos), S=S, F=F, H=H, D=D, B=B, TE=TE, WQ=WQ,
-                V=V, VQ=VQ, HB=HB)
+                V=V, VQ=VQ, HB=HB, HG=HG, WGF=WGF, WG=WG)
 
 
 def _local_maps(k, B, fm, fp, rev):
@@ -206,7 +228,7 @@ def tables_float(k, deg):
     import numpy as np
     t = tables_exact(k, deg)
     out = dict(k=k, deg=deg, nrt=t["nrt"], nd=t["nd"], nq=t["nq"])
-    for name in ("S", "F", "H", "D", "B", "TE", "WQ", "V", "VQ", "HB"):
+    for name in ("S", "F", "H", "D", "B", "TE", "WQ", "V", "VQ", "HB", "HG", "WGF", "WG"):
         def shape(x):
             return (len(x),) + shape(x[0]) if isinstance(x, list) else ()
         out[name] = np.array([float(v) for v in _flat(t[name])]).reshape(shape(t[name]))
@@ -247,6 +269,8 @@ def emit(path):
         arr("V", (3, nrt, 2), t["V"])
         arr("VQ", (18, 2, nh_, 3), t["VQ"])
         arr("HB", (3, 3, k, k), t["HB"])
+        arr("HG", (nd, nq), t["HG"])
+        arr("WG", (18, nh_, nd, 2), t["WG"])
         lines.append("};")
         lines.append("")
     # Lagrange P_d (Basix numbering, equispaced): monomial coefficients and inverse mass matrix
