@@ -43,14 +43,18 @@ def parse():
     ap.add_argument("--fused", type=int, default=1, help="all patch-size bins in one launch")
     ap.add_argument("--stress", action="store_true",
                     help="two rows + weak symmetry (BASELINE configs[3]); not the headline")
+    ap.add_argument("--ev", action="store_true",
+                    help="constrained-minimisation equilibrator (FluxEqlbEV); not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shuffle", type=int, default=None, help="seed for random local vertex order")
     return ap.parse_args()
 
 
-def compulsory_bytes_per_cell(k, nrhs):
-    """8 R [k(k+1) + k(k+1)/2 + k(k+2)] + 24 bytes per cell."""
-    return 8 * nrhs * (k * (k + 1) + k * (k + 1) // 2 + k * (k + 2)) + 24
+def compulsory_bytes_per_cell(k, nrhs, ev=False):
+    """8 R [k(k+1) + k(k+1)/2 + k(k+2)] + 24 bytes per cell; EV writes the
+    conforming space instead: 1.5 k facet + k^2-k interior DOFs per cell (136 B/cell at k=2)."""
+    nout = (1.5 * k + k * k - k) if ev else k * (k + 2)
+    return 8 * nrhs * (k * (k + 1) + k * (k + 1) // 2 + nout) + 24
 
 
 def main():
@@ -88,19 +92,28 @@ def main():
     else:
         G, f = make_compatible_data(mesh, k, ft, seed=20241003 + rank)
     dmesh = cpp.DeviceMesh(mesh)
-    eq = cpp.SemiExplicitEquilibrator(dmesh, k, nrhs, reconstruct_stress=args.stress)
-    if args.solver is not None:
-        eq.set_option("solver", args.solver)
-    if args.scatter is not None:
-        eq.set_option("scatter", args.scatter)
-    fused = bool(args.fused) and args.solver in (None, 1)
-    eq.set_option("fused", int(fused))
-    eq.set_boundary(ft, node_mask=part.node_mask)
+    if args.ev:
+        if world > 1 or args.stress:
+            raise SystemExit("--ev runs on one GPU without --stress")
+        eq = cpp.ConstrainedMinEquilibrator(dmesh, k, nrhs)
+        fused = True
+        eq.set_boundary(ft)
+        nout = eq.ndofs
+    else:
+        eq = cpp.SemiExplicitEquilibrator(dmesh, k, nrhs, reconstruct_stress=args.stress)
+        if args.solver is not None:
+            eq.set_option("solver", args.solver)
+        if args.scatter is not None:
+            eq.set_option("scatter", args.scatter)
+        fused = bool(args.fused) and args.solver in (None, 1)
+        eq.set_option("fused", int(fused))
+        eq.set_boundary(ft, node_mask=part.node_mask)
+        nout = mesh.ncells * nrt
     npatch_local = eq.num_patches
 
     d_G = torch.from_numpy(G).to(dev)
     d_f = torch.from_numpy(f).to(dev)
-    d_x = torch.zeros(nrhs * mesh.ncells * nrt, dtype=torch.float64, device=dev)
+    d_x = torch.zeros(nrhs * nout, dtype=torch.float64, device=dev)
     halo = dd.HaloExchange(part, nrt, dev) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -118,7 +131,11 @@ def main():
     torch.cuda.synchronize()
     x_host = d_x.cpu().numpy().copy()
     res = nrm = None
-    if world == 1 and not args.stress:
+    if world == 1 and args.ev:
+        from dolfinx_eqlb_amd.eqlb.conforming import conforming_to_broken
+        res, nrm = chk.divergence_residual(mesh, k, conforming_to_broken(mesh, k, x_host),
+                                           np.zeros_like(G), f)
+    elif world == 1 and not args.stress:
         res, nrm = chk.divergence_residual(mesh, k, x_host, G, f)
 
     for _ in range(args.warmup):
@@ -151,10 +168,10 @@ def main():
     ncells_bin = part.patch_cells_per_bin()  # patch-cells handled by each bin's launch
     dom = int(np.argmax(bins_ms))
     total_pc = float(sum(ncells_bin))
-    bytes_sweep = compulsory_bytes_per_cell(k, 1) * part.ncells_owned
+    bytes_sweep = compulsory_bytes_per_cell(k, 1, args.ev) * part.ncells_owned
     if fused:  # one launch does the whole sweep
         alg_bytes = float(bytes_sweep)
-        kname = f"k_se_patch_fused<K={k}>"
+        kname = f"k_ev_patch_fused<K={k}>" if args.ev else f"k_se_patch_fused<K={k}>"
         kernels_ms = {kname: bins_ms[0]}
     else:      # share of the sweep done by the dominant bin's launch
         alg_bytes = bytes_sweep * ncells_bin[dom] / total_pc
@@ -178,10 +195,12 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"Poisson {4 * n * n} triangles per GPU (crossed unit square {n}x{n}), "
-                        f"P{k} primal, FluxEqlbSE RT{k}, homogeneous Dirichlet, fp64",
+                        f"P{k} primal, {'FluxEqlbEV' if args.ev else 'FluxEqlbSE'} RT{k}, "
+                        f"homogeneous Dirichlet, fp64",
             "patches_per_gpu": npatch_local, "cells_per_gpu": int(part.ncells_owned),
             "nrhs": nrhs, "weak_symmetry": bool(args.stress), "partition": "node-ownership strips" if world > 1 else "none",
-            "solver": eq_solver_name(args.solver), "scatter": eq_scatter_name(args.scatter),
+            "solver": eq_solver_name(None if args.ev else args.solver),
+            "scatter": eq_scatter_name(None if args.ev else args.scatter),
         },
         "roofline": {
             "bound": "hbm",
@@ -198,7 +217,9 @@ def main():
         out["rhs_norm_L2"] = nrm
         out["div_residual_rel"] = res / nrm
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stress:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.ev:
+        out["cpu_baseline"] = cpu_baseline_ev(mesh, k, ft, G, f)
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stress:
         out["cpu_baseline"] = cpu_baseline(mesh, k, ft, G, f, npatch_local)
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -241,6 +262,31 @@ def cpu_baseline(mesh, k, ft, G, f, npatch):
             "sample": f"all {npatch} patches of the workload (one full sweep), best of 3, "
                       f"{best:.2f} s per sweep",
             "note": "CPU restatement of the reference algorithm (not the dolfinx_eqlb binary)"}
+
+
+def cpu_baseline_ev(mesh, k, ft, G, f):
+    """CPU restatement of the reference's EV algorithm (saddle-point LU per patch,
+    oracle/eqlb_oracle_ev.c) on a bounded sample: a contiguous range of nodes of the same mesh."""
+    from dolfinx_eqlb_amd.eqlb.conforming import conforming_dofmap
+    from oracle import oracle
+    cd, nd = conforming_dofmap(mesh, k)
+    x = np.zeros((1, nd))
+    nn = min(mesh.nnodes, 20000)
+    t0 = time.perf_counter()
+    oracle.ev_reconstruct(mesh, k, ft, G[None], f[None], cd, nd, flux_hdiv=x, node_range=(0, nn))
+    dt = time.perf_counter() - t0
+    # extend the sample to ~10 s of CPU work
+    nn2 = int(min(mesh.nnodes, max(nn, nn * 10.0 / max(dt, 1e-3))))
+    if nn2 > nn:
+        t0 = time.perf_counter()
+        oracle.ev_reconstruct(mesh, k, ft, G[None], f[None], cd, nd, flux_hdiv=x,
+                              node_range=(0, nn2))
+        dt = time.perf_counter() - t0
+        nn = nn2
+    return {"value": nn / dt, "unit": "patches/s", "cores": 1, "kind": "port",
+            "sample": f"patches of nodes 0..{nn} of the workload (one pass), {dt:.2f} s",
+            "note": "CPU restatement of the reference's EV algorithm (dense LU of the "
+                    "saddle-point system per patch); not the dolfinx_eqlb binary"}
 
 
 if __name__ == "__main__":

@@ -112,3 +112,17 @@ def test_flux_eqlb_ev_class(oracle_mod):
     assert _close(eq.get_reconstructed_fluxes(0), ref)
     with pytest.raises(RuntimeError):
         FluxEqlbEV(k, mesh, [f[0]], [G[0], G[0]])
+
+
+@pytest.mark.parametrize("name", ["ev_crossed2_k2_dirichlet", "ev_crossed4_k1_shuffled_neumann",
+                                  "ev_crossed4_k2_shuffled_neumann",
+                                  "ev_crossed4_k3_shuffled_neumann"])
+def test_ev_golden(name):
+    import os
+    from golden_util import load_case
+    from dolfinx_eqlb_amd import cpp
+    mesh, k, ft, G, f, expected = load_case(
+        os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    eq = cpp.ConstrainedMinEquilibrator(cpp.DeviceMesh(mesh), k, G.shape[0])
+    eq.set_boundary(ft)
+    assert _close(eq.equilibrate_host(G, f), expected)

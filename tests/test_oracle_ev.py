@@ -109,3 +109,18 @@ def test_conforming_frame_convention():
     # both cells of an interior facet give the same global DOF
     assert np.allclose(conforming_to_broken(mesh, k, np.r_[g, np.zeros(0)]), xb.reshape(-1),
                        atol=1e-13)
+
+
+EV_GOLDEN = ["ev_crossed2_k2_dirichlet", "ev_crossed4_k1_shuffled_neumann",
+             "ev_crossed4_k2_shuffled_neumann", "ev_crossed4_k3_shuffled_neumann"]
+
+
+@pytest.mark.parametrize("name", EV_GOLDEN)
+def test_ev_oracle_reproduces_golden(oracle_mod, name):
+    import os
+    from golden_util import load_case
+    mesh, k, ft, G, f, expected = load_case(
+        os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    cd, nd = conforming_dofmap(mesh, k)
+    x = oracle_mod.ev_reconstruct(mesh, k, ft, G, f, cd, nd)
+    assert np.abs(x - expected).max() <= 1e-12 * max(1.0, np.abs(expected).max())
