@@ -37,6 +37,95 @@ __device__ __forceinline__ double shfl_d(double v, int src_lane) { return __shfl
 
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; } // i >= j
 
+// ---- DPP lane exchange (VALU data path, no LDS round trip) --------------------------------------
+// gfx9 dpp_ctrl codes: quad_perm 0x00-0xff, row_shl:n 0x100+n, row_shr:n 0x110+n, wave_shl:1 0x130,
+// wave_shr:1 0x138, row_mirror 0x140, row_half_mirror 0x141.  Lanes without a source keep `v`.
+#ifndef EQLB_USE_DPP
+#define EQLB_USE_DPP 1
+#endif
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// value of lane - OFF (OFF = 1, 2, 4, 8 within a group of P <= 16 lanes aligned to 16-lane rows;
+// any P for OFF = 1); lanes whose source is outside the row / wave get their own value
+template <int P, int OFF>
+__device__ __forceinline__ double lane_down_d(double v, int gbase, int sub)
+{
+  if constexpr (EQLB_USE_DPP && P <= 16)
+    return dpp_d<0x110 + OFF>(v);
+  else if constexpr (EQLB_USE_DPP && OFF == 1)
+    return dpp_d<0x138>(v);
+  else
+    return __shfl(v, gbase + ((sub >= OFF) ? sub - OFF : sub), 64);
+}
+// value of lane + 1
+template <int P>
+__device__ __forceinline__ double lane_up1_d(double v, int gbase, int sub)
+{
+  if constexpr (EQLB_USE_DPP && P <= 16)
+    return dpp_d<0x101>(v);
+  else if constexpr (EQLB_USE_DPP)
+    return dpp_d<0x130>(v);
+  else
+    return __shfl(v, gbase + ((sub + 1 < P) ? sub + 1 : sub), 64);
+}
+// sum over the P lanes of a group, result in every lane
+template <int P>
+__device__ __forceinline__ double group_sum_d(double v, int gbase, int sub)
+{
+  if constexpr (EQLB_USE_DPP && P <= 16)
+  {
+    v += dpp_d<0xB1>(v); // quad_perm [1,0,3,2]
+    v += dpp_d<0x4E>(v); // quad_perm [2,3,0,1]
+    if constexpr (P >= 8)
+      v += dpp_d<0x141>(v); // row_half_mirror: lane i <-> 7 - i of each half row
+    if constexpr (P >= 16)
+      v += dpp_d<0x140>(v); // row_mirror: lane i <-> 15 - i
+    return v;
+  }
+  else
+  {
+#pragma unroll
+    for (int off = 1; off < P; off <<= 1)
+      v += __shfl(v, gbase + (sub ^ off), 64);
+    return v;
+  }
+}
+
+// ---- reciprocal / reciprocal square root: hardware seed + 2 Newton steps (full fp64 accuracy for
+// the well-scaled pivots of the patch systems; no denormal/overflow scaling as in the IEEE division)
+#ifndef EQLB_FAST_RCP
+#define EQLB_FAST_RCP 1
+#endif
+__device__ __forceinline__ double rcp_d(double x)
+{
+#if EQLB_FAST_RCP
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+__device__ __forceinline__ double rsqrt_d(double x)
+{
+#if EQLB_FAST_RCP
+  double y = __builtin_amdgcn_rsq(x);
+  // y <- y + y * (1 - x y^2) / 2
+  y = __builtin_fma(y * 0.5, __builtin_fma(-x * y, y, 1.0), y);
+  y = __builtin_fma(y * 0.5, __builtin_fma(-x * y, y, 1.0), y);
+  return y;
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+
 
 // ---- compile-time sizes of a (K, DEG, P) patch kernel ------------------------------------------
 template <int K, int DEG, int P>

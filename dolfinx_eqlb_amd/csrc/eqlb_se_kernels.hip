@@ -89,7 +89,8 @@ int fill_tables_host(int k, int deg, std::vector<double>& out)
 // what remains is the SPD minimisation of || sigma - hat_a G || over the patch-wise H(div=0) space,
 // i.e. the same matrix with the additional load (phi_h, hat_a G) (tensors HG, WG).
 template <int K, int DEG, int P, int SOLVER, int SCATTER, int BLOCK, int MODE = 0>
-__device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t block_id, double* lds)
+__device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t block_id, double* lds,
+                                              const bool tables_staged = false)
 {
   using Z = Sizes<K, DEG, P>;
   constexpr int KB = Z::KB, NADD = Z::NADD, NDIV = Z::NDIV, NRT = Z::NRT, ND = Z::ND, NQ = Z::NQ;
@@ -109,12 +110,15 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   (void)sA;
 
   const int tid = threadIdx.x;
-  for (int i = tid; i < Z::NTAB; i += BLOCK)
-    lds[i] = a.tables[Z::NS + i];
-  if constexpr (MODE == 1)
-    for (int i = tid; i < Z::NEV; i += BLOCK)
-      sHG[i] = a.tables[Z::OFF_HG + i];
-  __syncthreads();
+  if (!tables_staged)
+  {
+    for (int i = tid; i < Z::NTAB; i += BLOCK)
+      lds[i] = a.tables[Z::NS + i];
+    if constexpr (MODE == 1)
+      for (int i = tid; i < Z::NEV; i += BLOCK)
+        sHG[i] = a.tables[Z::OFF_HG + i];
+    __syncthreads();
+  }
 
   const int lane = tid & 63;
   const int sub = lane % P;          // lane within the patch group == cell index i
@@ -339,12 +343,35 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       // zero-order chain: inclusive prefix sum of R0 + J0(previous facet)
       const double Jprev0 = shfl_d(Jv[0], gbase + prev);
       double t = active ? (sgn * Rq[0] + (has_prev ? Jprev0 : 0.0)) : 0.0;
-#pragma unroll
-      for (int off = 1; off < P; off <<= 1)
       {
-        const double o = shfl_d(t, gbase + ((sub >= off) ? sub - off : sub));
-        if (sub >= off)
+        double o = lane_down_d<P, 1>(t, gbase, sub);
+        if (sub >= 1)
           t += o;
+        if constexpr (P > 2)
+        {
+          o = lane_down_d<P, 2>(t, gbase, sub);
+          if (sub >= 2)
+            t += o;
+        }
+        if constexpr (P > 4)
+        {
+          o = lane_down_d<P, 4>(t, gbase, sub);
+          if (sub >= 4)
+            t += o;
+        }
+        if constexpr (P > 8)
+        {
+          o = lane_down_d<P, 8>(t, gbase, sub);
+          if (sub >= 8)
+            t += o;
+        }
+#pragma unroll
+        for (int off = 16; off < P; off <<= 1)
+        {
+          o = shfl_d(t, gbase + ((sub >= off) ? sub - off : sub));
+          if (sub >= off)
+            t += o;
+        }
       }
       // prescribed outward moments of sigma_a on flux-BC end facets: pf * (hat_a g DOFs) - (hat_a G)
       // with the per-patch boundary DOFs of BoundaryData::calculate_patch_bc
@@ -437,7 +464,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
     // Te = sum_x g_x TE[ci][x], Le = -sum_x g_x WQ[ci][x] [mu_m; mu_p; sgn c_div], g = J^T J/|detJ|
     double Te[NH][NH], Le[NH];
     {
-      const double ia = active ? 1.0 / fabs(detJ) : 0.0;
+      const double ia = active ? rcp_d(fabs(detJ)) : 0.0;
       const double g0 = (J00 * J00 + J10 * J10) * ia, g1 = (J00 * J01 + J10 * J11) * ia,
                    g2 = (J01 * J01 + J11 * J11) * ia;
       const double* te = sTE + ci * 3 * NTE;
@@ -484,13 +511,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
     if constexpr (K == 1)
     {
       // only d: u = sum Le / sum Te  (se/PatchData.hpp:589)
-      double sa = Te[0][0], sl = Le[0];
-#pragma unroll
-      for (int off = 1; off < P; off <<= 1)
-      {
-        sa += shfl_d(sa, gbase + (sub ^ off));
-        sl += shfl_d(sl, gbase + (sub ^ off));
-      }
+      const double sa = group_sum_d<P>(Te[0][0], gbase, sub), sl = group_sum_d<P>(Le[0], gbase, sub);
       ul[0] = (d_fixed || !pvalid) ? 0.0 : sl / sa;
     }
     else if constexpr (SOLVER == 9)
@@ -694,7 +715,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       if constexpr (NADD == 1)
       {
         const double piv = active ? T[NC][NC] : 1.0;
-        const double ip = 1.0 / piv;
+        const double ip = rcp_d(piv);
         la = Lv[NC] * ip;
 #pragma unroll
         for (int h = 0; h < NC; ++h)
@@ -710,13 +731,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       }
       // (c) block row of facet E_sub: own minus-side blocks + plus-side blocks of the previous cell
       double Dg[KB][KB], bt[KB], rr[KB], Off[KB][KB];
-      double alpha = T[0][0], rd = Lv[0];
-#pragma unroll
-      for (int off = 1; off < P; off <<= 1)
-      {
-        alpha += shfl_d(alpha, gbase + (sub ^ off));
-        rd += shfl_d(rd, gbase + (sub ^ off));
-      }
+      double alpha = group_sum_d<P>(T[0][0], gbase, sub), rd = group_sum_d<P>(Lv[0], gbase, sub);
       if (d_fixed || !pvalid)
       {
         alpha = 1.0;
@@ -794,11 +809,11 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       double Ei[KB][KB], X[KB][1 + W], Y[KB][KB];
       auto finish_row = [&]() {
         if constexpr (KB == 1)
-          Ei[0][0] = 1.0 / Dp[0][0];
+          Ei[0][0] = rcp_d(Dp[0][0]);
         else
         {
           const double det = Dp[0][0] * Dp[1][1] - Dp[0][1] * Dp[1][0];
-          const double id = 1.0 / det;
+          const double id = rcp_d(det);
           Ei[0][0] = Dp[1][1] * id;
           Ei[1][1] = Dp[0][0] * id;
           Ei[0][1] = -Dp[0][1] * id;
@@ -855,7 +870,6 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
             P2[aa][c] = v;
           }
         }
-        const int src = gbase + ((sub > 0) ? sub - 1 : 0);
         const bool take = in_chain && sub == s;
 #pragma unroll
         for (int aa = 0; aa < KB; ++aa)
@@ -863,14 +877,14 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 #pragma unroll
           for (int bb = 0; bb < KB; ++bb)
           {
-            const double v = shfl_d(P1[aa][bb], src);
+            const double v = lane_down_d<P, 1>(P1[aa][bb], gbase, sub);
             if (take)
               Dp[aa][bb] -= v;
           }
 #pragma unroll
           for (int c = 0; c < 1 + W; ++c)
           {
-            const double v = shfl_d(P2[aa][c], src);
+            const double v = lane_down_d<P, 1>(P2[aa][c], gbase, sub);
             if (take)
               Rp[aa][c] -= v;
           }
@@ -898,21 +912,17 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         }
       }
 #pragma unroll
-      for (int off = 1; off < P; off <<= 1)
+      for (int c = 0; c < W; ++c)
       {
+        tred[c] = group_sum_d<P>(tred[c], gbase, sub);
 #pragma unroll
-        for (int c = 0; c < W; ++c)
-        {
-          tred[c] += shfl_d(tred[c], gbase + (sub ^ off));
-#pragma unroll
-          for (int c2 = 0; c2 <= c; ++c2)
-            Sred[c][c2] += shfl_d(Sred[c][c2], gbase + (sub ^ off));
-        }
+        for (int c2 = 0; c2 <= c; ++c2)
+          Sred[c][c2] = group_sum_d<P>(Sred[c][c2], gbase, sub);
       }
       double zz[W];
       {
         // Cholesky of Z - S (lower), then two triangular solves
-        double Lz[W][W];
+        double Lz[W][W], iLz[W];
 #pragma unroll
         for (int c = 0; c < W; ++c)
         {
@@ -933,8 +943,9 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
             status_local = pvalid ? 1 : status_local;
             dj = 1.0;
           }
-          const double lj = sqrt(dj), ilj = 1.0 / lj;
+          const double ilj = rsqrt_d(dj), lj = dj * ilj;
           Lz[j][j] = lj;
+          iLz[j] = ilj;
 #pragma unroll
           for (int i = j + 1; i < W; ++i)
           {
@@ -952,7 +963,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 #pragma unroll
           for (int q = 0; q < i; ++q)
             v -= Lz[i][q] * zz[q];
-          zz[i] = v / Lz[i][i];
+          zz[i] = v * iLz[i];
         }
 #pragma unroll
         for (int i = W - 1; i >= 0; --i)
@@ -961,7 +972,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 #pragma unroll
           for (int q = i + 1; q < W; ++q)
             v -= Lz[q][i] * zz[q];
-          zz[i] = v / Lz[i][i];
+          zz[i] = v * iLz[i];
         }
       }
       // (g) back substitution up the chain
@@ -981,7 +992,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         double xn[KB];
 #pragma unroll
         for (int aa = 0; aa < KB; ++aa)
-          xn[aa] = shfl_d(xs[aa], gbase + ((sub + 1 < P) ? sub + 1 : sub));
+          xn[aa] = lane_up1_d<P>(xs[aa], gbase, sub);
         if (in_chain && sub == s)
         {
 #pragma unroll
@@ -1117,37 +1128,51 @@ template <int K, int DEG, int SOLVER, int SCATTER>
 #ifndef EQLB_FUSED_WAVES
 #define EQLB_FUSED_WAVES 4
 #endif
+#ifndef EQLB_PERSIST_OVERSUB
+#define EQLB_PERSIST_OVERSUB 1
+#endif
 __global__ void __launch_bounds__(256, (K <= 2 ? EQLB_FUSED_WAVES : 1)) k_se_patch_fused(const SeArgs a0, const FusedBins fb)
 {
+  // PERSISTENT workgroups: the grid is sized to the chip (launch_fused_kd), every workgroup stages
+  // the reference tensors in LDS once and then strides over the 256-lane work blocks of all bins;
+  // its waves drift apart (no block barrier in the loop), so gathers of one wave overlap the
+  // arithmetic of the others.
   extern __shared__ double lds[];
-  const int64_t bid = blockIdx.x;
-  int b = 0;
-#pragma unroll
-  for (int i = 1; i < MAX_BINS; ++i)
-    if (bid >= fb.block_start[i])
-      b = i;
-  SeArgs a = a0;
-  a.npatch = fb.npatch[b];
-  a.slot_offset = fb.slot_offset[b];
-  a.patch_offset = fb.patch_offset[b];
-  const int64_t lb = bid - fb.block_start[b];
-  switch (b)
+  using Z = Sizes<K, DEG, 8>;
+  for (int i = threadIdx.x; i < Z::NTAB; i += 256)
+    lds[i] = a0.tables[Z::NS + i];
+  __syncthreads();
+  const int64_t nwork = fb.block_start[MAX_BINS];
+  for (int64_t bid = blockIdx.x; bid < nwork; bid += gridDim.x)
   {
-  case 0:
-    se_patch_body<K, DEG, 4, SOLVER, SCATTER, 256>(a, lb, lds);
-    break;
-  case 1:
-    se_patch_body<K, DEG, 8, SOLVER, SCATTER, 256>(a, lb, lds);
-    break;
-  case 2:
-    se_patch_body<K, DEG, 16, SOLVER, SCATTER, 256>(a, lb, lds);
-    break;
-  case 3:
-    se_patch_body<K, DEG, 32, SOLVER, SCATTER, 256>(a, lb, lds);
-    break;
-  default:
-    se_patch_body<K, DEG, 64, SOLVER, SCATTER, 256>(a, lb, lds);
-    break;
+    int b = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_BINS; ++i)
+      if (bid >= fb.block_start[i])
+        b = i;
+    SeArgs a = a0;
+    a.npatch = fb.npatch[b];
+    a.slot_offset = fb.slot_offset[b];
+    a.patch_offset = fb.patch_offset[b];
+    const int64_t lb = bid - fb.block_start[b];
+    switch (b)
+    {
+    case 0:
+      se_patch_body<K, DEG, 4, SOLVER, SCATTER, 256>(a, lb, lds, true);
+      break;
+    case 1:
+      se_patch_body<K, DEG, 8, SOLVER, SCATTER, 256>(a, lb, lds, true);
+      break;
+    case 2:
+      se_patch_body<K, DEG, 16, SOLVER, SCATTER, 256>(a, lb, lds, true);
+      break;
+    case 3:
+      se_patch_body<K, DEG, 32, SOLVER, SCATTER, 256>(a, lb, lds, true);
+      break;
+    default:
+      se_patch_body<K, DEG, 64, SOLVER, SCATTER, 256>(a, lb, lds, true);
+      break;
+    }
   }
 }
 
@@ -1301,9 +1326,24 @@ template <int K, int DEG>
 static int launch_fused_kd(int scatter, const SeArgs& a, const FusedBins& fb, hipStream_t stream)
 {
   const size_t lds_bytes = sizeof(double) * (size_t)Sizes<K, DEG, 8>::lds_doubles(256, 1);
-  const int64_t grid = fb.block_start[MAX_BINS];
-  if (grid == 0)
+  const int64_t nwork = fb.block_start[MAX_BINS];
+  if (nwork == 0)
     return 0;
+  // persistent grid: resident workgroups of the device (occupancy x CUs), at most the work
+  static int64_t resident[2] = {0, 0};
+  const int si = (scatter == EQLB_SCATTER_SLOTS) ? 0 : 1;
+  if (resident[si] == 0)
+  {
+    int dev = 0, ncu = 0, per_cu = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    const void* fn = si == 0 ? reinterpret_cast<const void*>(k_se_patch_fused<K, DEG, 1, 0>)
+                             : reinterpret_cast<const void*>(k_se_patch_fused<K, DEG, 1, 1>);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes) != hipSuccess || per_cu < 1)
+      per_cu = 1;
+    resident[si] = (int64_t)std::max(ncu, 1) * per_cu * EQLB_PERSIST_OVERSUB;
+  }
+  const int64_t grid = std::min(nwork, resident[si]);
   if (scatter == EQLB_SCATTER_SLOTS)
     hipLaunchKernelGGL((k_se_patch_fused<K, DEG, 1, 0>), dim3((unsigned)grid), dim3(256), lds_bytes, stream, a, fb);
   else

@@ -95,7 +95,7 @@ def test_one_cell_patch_is_an_error(oracle_mod):
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("name", sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+@pytest.mark.parametrize("name", sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith("ev_"))
                          if os.path.isdir(GOLDEN) else [])
 def test_golden_vectors(oracle_mod, name):
     from golden_util import load_case
