@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--n", type=int, default=500, help="squares per side and GPU (500 -> 1M triangles)")
     ap.add_argument("--k", type=int, default=2, help="RT degree")
     ap.add_argument("--solver", type=int, default=None)
-    ap.add_argument("--scatter", type=int, default=None)
+    ap.add_argument("--scatter", type=int, default=None,
+                    help="0 slots + reduction, 1 atomics, 2 tiled (default where available)")
     ap.add_argument("--fused", type=int, default=1, help="all patch-size bins in one launch")
     ap.add_argument("--stress", action="store_true",
                     help="two rows + weak symmetry (BASELINE configs[3]); not the headline")
@@ -103,13 +104,15 @@ def main():
         eq = cpp.SemiExplicitEquilibrator(dmesh, k, nrhs, reconstruct_stress=args.stress)
         if args.solver is not None:
             eq.set_option("solver", args.solver)
-        if args.scatter is not None:
-            eq.set_option("scatter", args.scatter)
-        fused = bool(args.fused) and args.solver in (None, 1)
+        if args.scatter is None:  # the library default
+            args.scatter = 2 if (k <= 2 and not args.stress and args.solver in (None, 1)) else 0
+        eq.set_option("scatter", args.scatter)
+        fused = (bool(args.fused) and args.solver in (None, 1)) or args.scatter == 2
         eq.set_option("fused", int(fused))
         eq.set_boundary(ft, node_mask=part.node_mask)
         nout = mesh.ncells * nrt
     npatch_local = eq.num_patches
+    tiling = eq.tiling_info() if (not args.ev and args.scatter == 2) else None
 
     d_G = torch.from_numpy(G).to(dev)
     d_f = torch.from_numpy(f).to(dev)
@@ -171,7 +174,8 @@ def main():
     bytes_sweep = compulsory_bytes_per_cell(k, 1, args.ev) * part.ncells_owned
     if fused:  # one launch does the whole sweep
         alg_bytes = float(bytes_sweep)
-        kname = f"k_ev_patch_fused<K={k}>" if args.ev else f"k_se_patch_fused<K={k}>"
+        kname = f"k_ev_patch_fused<K={k}>" if args.ev else (
+            f"k_se_patch_tiled<K={k}>" if args.scatter == 2 else f"k_se_patch_fused<K={k}>")
         kernels_ms = {kname: bins_ms[0]}
     else:      # share of the sweep done by the dominant bin's launch
         alg_bytes = bytes_sweep * ncells_bin[dom] / total_pc
@@ -212,6 +216,8 @@ def main():
             "all_kernels_ms": kernels_ms | ({"reduce_slots": reduce_ms} if reduce_ms > 0 else {}),
         },
     }
+    if tiling is not None:
+        out["config"]["tiling"] = tiling
     if res is not None:
         out["div_residual_L2"] = res
         out["rhs_norm_L2"] = nrm
@@ -243,7 +249,7 @@ def eq_solver_name(v):
 
 
 def eq_scatter_name(v):
-    return {None: "slots", 0: "slots", 1: "atomic"}[v]
+    return {None: "slots", 0: "slots", 1: "atomic", 2: "tiled"}[v]
 
 
 def cpu_baseline(mesh, k, ft, G, f, npatch):

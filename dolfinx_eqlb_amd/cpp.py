@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("EQLB_AMD_LIB", os.path.join(_HERE, "libeqlb_amd.so"))
 
 MEM_HOST, MEM_DEVICE = 0, 1
 SOLVER_LDS_CHOLESKY, SOLVER_SHUFFLE = 0, 1
-SCATTER_SLOTS, SCATTER_ATOMIC = 0, 1
+SCATTER_SLOTS, SCATTER_ATOMIC, SCATTER_TILED = 0, 1, 2
 
 # every symbol include/eqlb.h declares (tests check that the library exports all of them)
 EXPORTED_SYMBOLS = [
@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "eqlb_project_dg", "eqlb_se_equilibrate_with_kornconst",
     "eqlb_ev_create", "eqlb_ev_destroy", "eqlb_ev_set_option", "eqlb_ev_set_dofmap",
     "eqlb_ev_num_dofs", "eqlb_ev_set_boundary", "eqlb_ev_equilibrate", "eqlb_ev_num_patches",
-    "eqlb_ev_last_kernel_ms",
+    "eqlb_ev_last_kernel_ms", "eqlb_se_tiling_info",
 ]
 
 _lib = None
@@ -142,6 +142,13 @@ class SemiExplicitEquilibrator:
     @property
     def num_patches(self):
         return int(lib().eqlb_se_num_patches(self._h))
+
+    def tiling_info(self):
+        """dict(ntiles, cells_per_tile, patch_instances, lane_slots) of the tiled launch."""
+        v = [C.c_int64(0) for _ in range(4)]
+        _check(lib().eqlb_se_tiling_info(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("ntiles", "cells_per_tile", "patch_instances", "lane_slots"),
+                        [int(x.value) for x in v]))
 
     def equilibrate_host(self, flux_dg, rhs_dg, flux_hdiv=None):
         """Host numpy arrays in/out; flux_hdiv is accumulated (+=) like the reference."""

@@ -63,7 +63,173 @@ void free_boundary(eqlb_se* h)
   dfree(h->pn);
   dfree(h->pflag);
   dfree(h->slots); // re-zeroed on the next call (node_mask may have changed)
+  dfree(h->t_tiles);
+  dfree(h->t_tile_cells);
+  dfree(h->t_slot_cell);
+  dfree(h->t_slot_info);
+  dfree(h->t_pn);
+  dfree(h->t_pflag);
+  h->ntiles = 0;
   h->boundary_set = false;
+}
+// Recursive coordinate bisection of the cell centroids into chunks of exactly `tc` cells (the last
+// one may be short): compact tiles keep the share of rim patches, which are solved by every tile
+// they touch, small.
+struct TileItem
+{
+  double x, y;
+  int32_t cell;
+};
+
+void rcb_split(TileItem* a, int64_t n, int64_t ntile, int tc)
+{
+  if (ntile <= 1 || n <= tc)
+    return;
+  double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+  for (int64_t i = 0; i < n; ++i)
+  {
+    lo[0] = std::min(lo[0], a[i].x);
+    hi[0] = std::max(hi[0], a[i].x);
+    lo[1] = std::min(lo[1], a[i].y);
+    hi[1] = std::max(hi[1], a[i].y);
+  }
+  const int64_t tl = ntile / 2;
+  const int64_t nl = std::min<int64_t>(n, tl * tc);
+  if (hi[0] - lo[0] >= hi[1] - lo[1])
+    std::nth_element(a, a + nl, a + n, [](const TileItem& p, const TileItem& q) {
+      return p.x < q.x || (p.x == q.x && p.cell < q.cell);
+    });
+  else
+    std::nth_element(a, a + nl, a + n, [](const TileItem& p, const TileItem& q) {
+      return p.y < q.y || (p.y == q.y && p.cell < q.cell);
+    });
+  rcb_split(a, nl, tl, tc);
+  rcb_split(a + nl, n - nl, ntile - tl, tc);
+}
+
+// Tiled SoA of the plain flux equilibration (EQLB_SCATTER_TILED): cells bisected recursively by
+// their centroids into tiles of TC cells; a tile lists every (masked-in) node of its cells.
+int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin, eqlb::BuildArgs a)
+{
+  const eqlb::DeviceMesh& m = h->mesh->m;
+  const int32_t nc = m.ncells;
+  const int TC = eqlb::tile_cells_of(h->k);
+  std::vector<TileItem> items(nc);
+  for (int32_t c = 0; c < nc; ++c)
+  {
+    const int32_t* cn = &m.h_cell_nodes[3 * (size_t)c];
+    double cx = 0.0, cy = 0.0;
+    for (int j = 0; j < 3; ++j)
+    {
+      cx += m.h_x[3 * (size_t)cn[j]];
+      cy += m.h_x[3 * (size_t)cn[j] + 1];
+    }
+    items[c] = {cx, cy, c};
+  }
+  const int32_t ntiles = (nc + TC - 1) / TC;
+  rcb_split(items.data(), nc, ntiles, TC);
+  std::vector<int32_t> tile_cells((size_t)ntiles * TC, -1), cell_tile(nc), cell_pos(nc);
+  for (int32_t p = 0; p < nc; ++p)
+  {
+    const int32_t c = items[p].cell;
+    tile_cells[p] = c;
+    cell_tile[c] = p / TC;
+    cell_pos[c] = p;
+  }
+  std::vector<eqlb::TileDesc> tiles(ntiles);
+  std::vector<int32_t> inst_node, inst_slot, inst_tile, stamp(m.nnodes, -1);
+  std::vector<int32_t> blist[eqlb::MAX_BINS];
+  int64_t slotctr = 0;
+  for (int32_t t = 0; t < ntiles; ++t)
+  {
+    for (auto& l : blist)
+      l.clear();
+    for (int q = 0; q < TC; ++q)
+    {
+      const int32_t c = tile_cells[(size_t)t * TC + q];
+      if (c < 0)
+        continue;
+      for (int j = 0; j < 3; ++j)
+      {
+        const int32_t nd = m.h_cell_nodes[3 * (size_t)c + j];
+        if (node_bin[nd] < 0 || stamp[nd] == t)
+          continue;
+        stamp[nd] = t;
+        blist[node_bin[nd]].push_back(nd);
+      }
+    }
+    for (int b = 0; b < eqlb::MAX_BINS; ++b)
+    {
+      tiles[t].slot_start[b] = (int32_t)slotctr;
+      tiles[t].patch_start[b] = (int32_t)inst_node.size();
+      tiles[t].npatch[b] = (int32_t)blist[b].size();
+      for (int32_t nd : blist[b])
+      {
+        inst_node.push_back(nd);
+        inst_slot.push_back((int32_t)slotctr);
+        inst_tile.push_back(t);
+        slotctr += eqlb::BIN_P[b];
+      }
+      slotctr = (slotctr + 63) & ~(int64_t)63;
+      if (slotctr > 0x7fffff00)
+        return fail(EQLB_ERR_UNSUPPORTED, "tiled patch SoA exceeds 2^31 lane slots");
+    }
+  }
+  h->ntiles = ntiles;
+  h->tile_tc = TC;
+  h->t_nslots = slotctr;
+  h->t_npatch = (int64_t)inst_node.size();
+  int32_t *d_inode = nullptr, *d_islot = nullptr, *d_itile = nullptr, *d_ctile = nullptr, *d_cpos = nullptr;
+  int st = 0;
+  st |= upload(&h->t_tiles, tiles.data(), tiles.size());
+  st |= upload(&h->t_tile_cells, tile_cells.data(), tile_cells.size());
+  st |= upload<int32_t>(&h->t_slot_cell, nullptr, (size_t)std::max<int64_t>(slotctr, 1));
+  st |= upload<uint32_t>(&h->t_slot_info, nullptr, (size_t)std::max<int64_t>(slotctr, 1));
+  st |= upload<uint8_t>(&h->t_pn, nullptr, (size_t)std::max<int64_t>(h->t_npatch, 1));
+  st |= upload<uint8_t>(&h->t_pflag, nullptr, (size_t)std::max<int64_t>(h->t_npatch, 1) * h->nrhs);
+  st |= upload(&d_inode, inst_node.data(), std::max<size_t>(inst_node.size(), 1));
+  st |= upload(&d_islot, inst_slot.data(), std::max<size_t>(inst_slot.size(), 1));
+  st |= upload(&d_itile, inst_tile.data(), std::max<size_t>(inst_tile.size(), 1));
+  st |= upload(&d_ctile, cell_tile.data(), cell_tile.size());
+  st |= upload(&d_cpos, cell_pos.data(), cell_pos.size());
+  hipError_t e = hipSuccess;
+  if (!st)
+  {
+    e = hipMemset(h->t_slot_cell, 0xff, sizeof(int32_t) * std::max<int64_t>(slotctr, 1));
+    if (e == hipSuccess)
+      e = hipMemset(h->t_slot_info, 0, sizeof(uint32_t) * std::max<int64_t>(slotctr, 1));
+    a.ninst = h->t_npatch;
+    a.inst_node = d_inode;
+    a.inst_slot = d_islot;
+    a.inst_tile = d_itile;
+    a.cell_tile = d_ctile;
+    a.cell_pos = d_cpos;
+    a.tile_cells = TC;
+    a.npatch_total = h->t_npatch;
+    a.slot_cell = h->t_slot_cell;
+    a.slot_info = h->t_slot_info;
+    a.pn = h->t_pn;
+    a.pflag = h->t_pflag;
+    a.stride = 0;
+    a.ex_ncells = nullptr;
+    if (e == hipSuccess && a.ninst > 0)
+    {
+      eqlb::launch_build_patches(a, nullptr);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+      e = hipDeviceSynchronize();
+  }
+  dfree(d_inode);
+  dfree(d_islot);
+  dfree(d_itile);
+  dfree(d_ctile);
+  dfree(d_cpos);
+  if (st)
+    return EQLB_ERR_DEVICE;
+  if (e != hipSuccess)
+    return fail(EQLB_ERR_DEVICE, "tiled patch builder: %s", hipGetErrorString(e));
+  return EQLB_OK;
 }
 } // namespace
 
@@ -106,6 +272,8 @@ int eqlb_mesh_create(int32_t nnodes, int32_t ncells, int32_t nfacets, const doub
     d.h_node_nfcts[i] = node_facets_offsets[i + 1] - node_facets_offsets[i];
     d.ncells_max = std::max(d.ncells_max, d.h_node_ncells[i]);
   }
+  d.h_x.assign(x, x + (size_t)nnodes * 3);
+  d.h_cell_nodes.assign(cell_nodes, cell_nodes + (size_t)ncells * 3);
   int st = 0;
   st |= upload(&d.x, x, (size_t)nnodes * 3);
   st |= upload(&d.cell_nodes, cell_nodes, (size_t)ncells * 3);
@@ -184,6 +352,8 @@ int eqlb_se_create(eqlb_mesh_t* mesh, int32_t k, int32_t degree_dg, int32_t nrhs
   h->deg = degree_dg;
   h->nrhs = nrhs;
   h->stress = reconstruct_stress ? 1 : 0;
+  // default result path: tiled launch where it is the fastest (measured)
+  h->scatter = EQLB_SCATTER_AUTO;
   h->nrt = k * (k + 2);
   h->nd = (degree_dg + 1) * (degree_dg + 2) / 2;
   int st = upload(&h->tables, tab.data(), tab.size());
@@ -232,7 +402,8 @@ int eqlb_se_set_option(eqlb_se_t* h, const char* key, int32_t value)
   }
   else if (!strcmp(key, "scatter"))
   {
-    if (value != EQLB_SCATTER_SLOTS && value != EQLB_SCATTER_ATOMIC)
+    if (value != EQLB_SCATTER_SLOTS && value != EQLB_SCATTER_ATOMIC && value != EQLB_SCATTER_TILED
+        && value != EQLB_SCATTER_AUTO)
       return fail(EQLB_ERR_INVALID_ARGUMENT, "unknown scatter mode %d", value);
     h->scatter = value;
   }
@@ -357,6 +528,12 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
   eqlb::launch_build_patches(a, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
+  if (h->mode == 0 && !h->stress)
+  {
+    const int stt = build_tiles(h, node_bin, a);
+    if (stt)
+      return stt;
+  }
   h->boundary_set = true;
   return EQLB_OK;
 }
@@ -394,6 +571,22 @@ int eqlb_se_equilibrate_with_kornconst(eqlb_se_t* h, const double* flux_dg, cons
 }
 
 int64_t eqlb_se_num_patches(const eqlb_se_t* h) { return h ? h->npatch_total : 0; }
+
+int eqlb_se_tiling_info(const eqlb_se_t* h, int64_t* ntiles, int64_t* cells_per_tile,
+                        int64_t* npatch_instances, int64_t* nlane_slots)
+{
+  if (!h || !h->boundary_set)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_tiling_info: set the boundary first");
+  if (ntiles)
+    *ntiles = h->ntiles;
+  if (cells_per_tile)
+    *cells_per_tile = h->tile_tc;
+  if (npatch_instances)
+    *npatch_instances = h->t_npatch;
+  if (nlane_slots)
+    *nlane_slots = h->t_nslots;
+  return EQLB_OK;
+}
 
 int eqlb_se_export_patches(eqlb_se_t* h, int32_t stride, int32_t* ncells, int32_t* cells,
                            int32_t* fcts, int8_t* fcts_local, int8_t* inodes_local,
@@ -479,11 +672,19 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const size_t n_g = (size_t)h->nrhs * m.ncells * h->nd * 2;
   const size_t n_f = (size_t)h->nrhs * m.ncells * h->nd;
+  // EQLB_SCATTER_AUTO: the tiled launch where it applies and is the fastest (k <= 2, plain flux
+  // equilibration, shuffle solver), else slots + reduction
+  int scatter_eff = h->scatter;
+  if (scatter_eff == EQLB_SCATTER_AUTO)
+    scatter_eff = (h->mode == 0 && !h->stress && h->k <= 2 && h->solver == EQLB_SOLVER_SHUFFLE && h->ntiles > 0)
+                      ? EQLB_SCATTER_TILED
+                      : EQLB_SCATTER_SLOTS;
+  h->scatter_last = scatter_eff;
   const size_t n_slot = (size_t)h->nrhs * m.ncells * h->nrt;
   // EV mode writes conforming DOFs unless the broken layout is requested
   const bool ev_conf = h->mode == 1 && h->ev_output == 0;
   const size_t n_x = ev_conf ? (size_t)h->nrhs * h->ev_ndofs : n_slot;
-  if (h->mode == 1 && (h->scatter != EQLB_SCATTER_SLOTS || h->solver != EQLB_SOLVER_SHUFFLE))
+  if (h->mode == 1 && (scatter_eff != EQLB_SCATTER_SLOTS || h->solver != EQLB_SOLVER_SHUFFLE))
     return fail(EQLB_ERR_UNSUPPORTED, "EV equilibration runs with the shuffle solver and slot scatter");
 
   const double *d_g = flux_dg, *d_f = rhs_dg;
@@ -506,7 +707,7 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
   else if (memspace != EQLB_MEM_DEVICE)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_equilibrate: unknown memory space");
 
-  if (h->scatter == EQLB_SCATTER_SLOTS && !h->slots)
+  if (scatter_eff == EQLB_SCATTER_SLOTS && !h->slots)
   {
     if (upload<double>(&h->slots, nullptr, n_slot * 3))
       return EQLB_ERR_DEVICE;
@@ -535,13 +736,38 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
   a.flux_dg = d_g;
   a.rhs_dg = d_f;
   a.bvals = h->bvals;
-  a.out = (h->scatter == EQLB_SCATTER_SLOTS) ? h->slots : d_x;
+  a.out = (scatter_eff == EQLB_SCATTER_SLOTS) ? h->slots : d_x;
   a.status = h->status;
   a.npatch_total = h->npatch_total;
   a.ncells = m.ncells;
   a.nrhs = h->nrhs;
 
-  if (h->mode == 1 || (h->fused && h->solver == EQLB_SOLVER_SHUFFLE))
+  const bool tiled = scatter_eff == EQLB_SCATTER_TILED;
+  if (tiled)
+  {
+    if (h->mode != 0 || h->stress || h->solver != EQLB_SOLVER_SHUFFLE || h->ntiles == 0)
+      return fail(EQLB_ERR_UNSUPPORTED,
+                  "the tiled scatter is available for plain flux equilibration with the shuffle solver");
+    eqlb::TileArgs ta{h->t_tiles, h->t_tile_cells, h->ntiles, h->tile_tc};
+    a.slot_cell = h->t_slot_cell;
+    a.slot_info = h->t_slot_info;
+    a.pn = h->t_pn;
+    a.pflag = h->t_pflag;
+    a.npatch_total = h->t_npatch;
+    a.out = d_x;
+    for (int r = 0; r < h->nrhs; ++r)
+    {
+      a.rhs = r;
+      if (evs && r == 0)
+        HIP_TRY(hipEventRecord(evs[0], stream));
+      const int st = eqlb::launch_se_patch_tiled(h->k, h->deg, a, ta, stream);
+      if (st)
+        return fail(st, "tiled patch kernel launch failed (k=%d)", h->k);
+    }
+    if (evs)
+      HIP_TRY(hipEventRecord(evs[1], stream));
+  }
+  else if (h->mode == 1 || (h->fused && h->solver == EQLB_SOLVER_SHUFFLE))
   {
     // all bins in one launch; timing slot 0 holds the fused kernel
     eqlb::FusedBins fb{};
@@ -561,7 +787,7 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
       if (evs && r == 0)
         HIP_TRY(hipEventRecord(evs[0], stream));
       const int st = (h->mode == 1) ? eqlb::launch_ev_patch_fused(h->k, a, fb, stream)
-                                    : eqlb::launch_se_patch_fused(h->k, h->deg, h->scatter, a, fb, stream);
+                                    : eqlb::launch_se_patch_fused(h->k, h->deg, scatter_eff, a, fb, stream);
       if (st)
         return fail(st, "fused patch kernel launch failed (k=%d)", h->k);
     }
@@ -581,7 +807,7 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
     for (int r = 0; r < h->nrhs; ++r)
     {
       a.rhs = r;
-      const int st = eqlb::launch_se_patch(h->k, h->deg, h->bins[b].P, h->solver, h->scatter, a, stream);
+      const int st = eqlb::launch_se_patch(h->k, h->deg, h->bins[b].P, h->solver, scatter_eff, a, stream);
       if (st)
         return fail(st, "patch kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
     }
@@ -592,7 +818,7 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
   {
     // weak symmetry of rows 0, 1 on the patch-local stresses held in the slots
     // (se/reconstruction.hpp:237-270; grouped boundary patches :170-234 are not implemented)
-    if (h->scatter != EQLB_SCATTER_SLOTS)
+    if (scatter_eff != EQLB_SCATTER_SLOTS)
       return fail(EQLB_ERR_UNSUPPORTED, "stress equilibration needs the slot scatter");
     for (int b = 0; b < eqlb::MAX_BINS; ++b)
     {
@@ -606,7 +832,7 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
         return fail(st, "weak-symmetry kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
     }
   }
-  if (h->scatter == EQLB_SCATTER_SLOTS)
+  if (scatter_eff == EQLB_SCATTER_SLOTS)
   {
     if (evs)
       HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS], stream));
@@ -643,10 +869,11 @@ double eqlb_se_last_kernel_ms(const eqlb_se_t* h, int32_t which)
   // (at most the last EV_RING calls).  Synchronises with the recorded events.
   if (!h || !h->ev || h->ev_calls == 0 || which < 0 || which > eqlb::MAX_BINS)
     return 0.0;
-  const bool fused_run = h->mode == 1 || (h->fused && h->solver == EQLB_SOLVER_SHUFFLE);
+  const bool fused_run = h->mode == 1 || h->scatter_last == EQLB_SCATTER_TILED
+                         || (h->fused && h->solver == EQLB_SOLVER_SHUFFLE);
   if (which < eqlb::MAX_BINS && ((fused_run && which != 0) || (!fused_run && h->bins[which].npatch == 0)))
     return 0.0;
-  if (which == eqlb::MAX_BINS && h->scatter != EQLB_SCATTER_SLOTS)
+  if (which == eqlb::MAX_BINS && h->scatter_last != EQLB_SCATTER_SLOTS)
     return 0.0;
   const int64_t nset = std::min<int64_t>(h->ev_calls, eqlb_se::EV_RING);
   double sum = 0.0;
@@ -758,6 +985,7 @@ int eqlb_ev_create(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, eqlb_ev_t** handl
   if (st)
     return st;
   se->mode = 1;
+  se->scatter = EQLB_SCATTER_SLOTS;
   se->ev_ndofs = (int64_t)mesh->m.nfacets * k + (int64_t)mesh->m.ncells * (k * k - k);
   eqlb_ev* h = new eqlb_ev();
   h->se = se;

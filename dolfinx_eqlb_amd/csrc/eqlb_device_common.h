@@ -127,6 +127,15 @@ __device__ __forceinline__ double rsqrt_d(double x)
 }
 
 
+// A/B switches of the memory path: cooperative LDS staging of the input
+// rows (LDS-DMA) and of the output slot rows; off by default (measured slower)
+#ifndef EQLB_STAGE_IN
+#define EQLB_STAGE_IN 0
+#endif
+#ifndef EQLB_STAGE_OUT
+#define EQLB_STAGE_OUT 0
+#endif
+
 // ---- compile-time sizes of a (K, DEG, P) patch kernel ------------------------------------------
 template <int K, int DEG, int P>
 struct Sizes
@@ -158,7 +167,7 @@ struct Sizes
   static constexpr int NCF = 8 * ND / FB;
   static constexpr int STG_G = 64 * ND * 2, STG_F = 64 * ND, STG_J = 64 * 4;
   static constexpr int STG_IN = STG_G + STG_F + STG_J, STG_OUT = 64 * NRT;
-  static constexpr int STG = (STG_IN > STG_OUT) ? STG_IN : STG_OUT;
+  static constexpr int STG = (EQLB_STAGE_IN || EQLB_STAGE_OUT) ? ((STG_IN > STG_OUT) ? STG_IN : STG_OUT) : 0;
   static constexpr int lds_doubles(int block, int solver, int mode = 0)
   {
     return NTAB + (mode ? NEV : 0) + (block / 64) * STG

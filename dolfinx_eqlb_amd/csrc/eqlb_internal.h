@@ -18,6 +18,9 @@ namespace eqlb
 //   bit 7 rev_p  E_a reversed w.r.t. T_{a+1}
 constexpr uint32_t INFO_FM_SHIFT = 0, INFO_FP_SHIFT = 2, INFO_LN_SHIFT = 4;
 constexpr uint32_t INFO_REV_M = 1u << 6, INFO_REV_P = 1u << 7;
+//   bits 8-31 (tiled SoA only): 1 + position of the cell among the cells owned by the lane's
+//   tile, 0 if the cell belongs to another tile (halo lane: computed, not accumulated)
+constexpr uint32_t INFO_LOCAL_SHIFT = 8;
 
 // per-(rhs, patch) flags
 constexpr uint8_t PFLAG_INTERIOR = 1, PFLAG_BC0 = 2, PFLAG_BCN = 4;
@@ -35,8 +38,9 @@ struct DeviceMesh
   int32_t *facet_cells_off = nullptr, *facet_cells = nullptr;
   int32_t *node_cells_off = nullptr, *node_facets_off = nullptr, *node_facets = nullptr;
   uint8_t* facet_perm = nullptr;
-  // host copies needed for binning
-  std::vector<int32_t> h_node_ncells, h_node_nfcts;
+  // host copies needed for binning / tiling
+  std::vector<int32_t> h_node_ncells, h_node_nfcts, h_cell_nodes;
+  std::vector<double> h_x;
 };
 
 struct Bin
@@ -74,6 +78,23 @@ struct FusedBins
   int64_t npatch[MAX_BINS], slot_offset[MAX_BINS], patch_offset[MAX_BINS];
 };
 
+// Tiled launch (EQLB_SCATTER_TILED): a workgroup owns TC cells (a chunk of the Morton-sorted cell
+// list), solves every patch that touches one of them and accumulates the three vertex
+// contributions of its cells in LDS, so neither the slot buffer nor the reduction pass exist.
+struct TileDesc
+{
+  int32_t slot_start[MAX_BINS]; // first lane slot of the tile's patches of bin b (multiple of 64)
+  int32_t patch_start[MAX_BINS];
+  int32_t npatch[MAX_BINS];
+};
+
+struct TileArgs
+{
+  const TileDesc* tiles;
+  const int32_t* tile_cells; // [ntiles][tc] owned cells (-1: padding)
+  int32_t ntiles, tc;
+};
+
 struct BuildArgs
 {
   int32_t nnodes, nfacets, nrhs;
@@ -88,6 +109,15 @@ struct BuildArgs
   uint32_t* slot_info;
   uint8_t* pn;
   uint8_t* pflag;
+  // instance mode (tiled SoA): thread i builds the patch of node inst_node[i] at slot inst_slot[i]
+  // as patch i of tile inst_tile[i]; nullptr: one patch per node (node_slot / node_patch)
+  int64_t ninst;
+  const int32_t* inst_node;
+  const int32_t* inst_slot;
+  const int32_t* inst_tile;
+  const int32_t* cell_tile; // [ncells] owning tile
+  const int32_t* cell_pos;  // [ncells] position in the tile-sorted cell list
+  int32_t tile_cells;       // cells per tile
   // optional export in OrientedPatch layout (nullptr: off)
   int32_t stride;
   int32_t *ex_ncells, *ex_cells, *ex_fcts;
@@ -102,6 +132,8 @@ int launch_se_patch(int k, int deg, int P, int solver, int scatter, const SeArgs
                     hipStream_t stream);
 int launch_se_patch_fused(int k, int deg, int scatter, const SeArgs& a, const FusedBins& fb,
                           hipStream_t stream);
+int launch_se_patch_tiled(int k, int deg, const SeArgs& a, const TileArgs& t, hipStream_t stream);
+int tile_cells_of(int k);
 int launch_se_weaksym(int k, int P, const SeArgs& a, hipStream_t stream);
 int launch_ev_patch_fused(int k, const SeArgs& a, const FusedBins& fb, hipStream_t stream);
 // conforming <-> broken layout of the EV equilibrator (eqlb_ev.hip); cell_dofs may be nullptr
@@ -140,7 +172,8 @@ struct eqlb_se
   eqlb_mesh* mesh = nullptr;
   int k = 0, deg = 0, nrhs = 0, stress = 0;
   int nrt = 0, nd = 0;
-  int solver = EQLB_SOLVER_SHUFFLE, scatter = EQLB_SCATTER_SLOTS, timing = 0, fused = 1;
+  int solver = EQLB_SOLVER_SHUFFLE, scatter = EQLB_SCATTER_AUTO, timing = 0, fused = 1;
+  int scatter_last = EQLB_SCATTER_SLOTS; // scatter mode the last equilibrate call resolved to
   int mode = 0;                     // 1: constrained-minimisation (EV) patch problems
   int ev_output = 0;                // EV: 0 conforming DOFs, 1 broken hierarchic RT_k layout
   int32_t* ev_cell_dofs = nullptr;  // EV: device copy of the caller's dofmap or nullptr (default)
@@ -159,6 +192,13 @@ struct eqlb_se
   uint32_t* slot_info = nullptr;
   uint8_t* pn = nullptr;
   uint8_t* pflag = nullptr;
+  // tiled SoA (plain SE, EQLB_SCATTER_TILED)
+  int32_t ntiles = 0, tile_tc = 0;
+  int64_t t_nslots = 0, t_npatch = 0;
+  eqlb::TileDesc* t_tiles = nullptr;
+  int32_t *t_tile_cells = nullptr, *t_slot_cell = nullptr;
+  uint32_t* t_slot_info = nullptr;
+  uint8_t *t_pn = nullptr, *t_pflag = nullptr;
   double* slots = nullptr;          // [nrhs][ncells][3][nrt]
   int32_t* status = nullptr;
   // staging for host-memory calls

@@ -37,16 +37,25 @@ __device__ inline int32_t next_facet(const BuildArgs& a, int32_t cell, int lf, i
 
 __global__ void __launch_bounds__(256) k_build_patches(BuildArgs a)
 {
-  const int32_t node = blockIdx.x * blockDim.x + threadIdx.x;
-  if (node >= a.nnodes)
+  const int64_t tid_g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool inst = (a.inst_node != nullptr);
+  if (tid_g >= (inst ? a.ninst : (int64_t)a.nnodes))
     return;
+  const int32_t node = inst ? a.inst_node[tid_g] : (int32_t)tid_g;
+  const int32_t tile = inst ? a.inst_tile[tid_g] : -1;
+  // tiled SoA: 1 + local index of an owned cell in the upper bits of the descriptor
+  auto local_bits = [&](int32_t c) -> uint32_t {
+    if (!inst || a.cell_tile[c] != tile)
+      return 0u;
+    return (uint32_t)(a.cell_pos[c] - tile * a.tile_cells + 1) << INFO_LOCAL_SHIFT;
+  };
   const int n = a.node_cells_off[node + 1] - a.node_cells_off[node];
   const int nf = a.node_facets_off[node + 1] - a.node_facets_off[node];
   const int32_t* nfcts = a.node_facets + a.node_facets_off[node];
   const bool interior = (nf == n);
-  const int64_t slot0 = a.node_slot ? a.node_slot[node] : -1;
-  const int64_t patch = (slot0 >= 0) ? a.node_patch[node] : -1;
-  const bool ex = (a.ex_ncells != nullptr);
+  const int64_t slot0 = inst ? (int64_t)a.inst_slot[tid_g] : (a.node_slot ? a.node_slot[node] : -1);
+  const int64_t patch = inst ? tid_g : ((slot0 >= 0) ? a.node_patch[node] : -1);
+  const bool ex = (a.ex_ncells != nullptr) && !inst;
   const int64_t exo = (int64_t)node * a.stride;
 
   if (ex)
@@ -120,7 +129,7 @@ __global__ void __launch_bounds__(256) k_build_patches(BuildArgs a)
 
     uint32_t info = ((uint32_t)fm_carry << INFO_FM_SHIFT) | ((uint32_t)lf_a << INFO_FP_SHIFT)
                     | ((uint32_t)ln_a << INFO_LN_SHIFT) | (revm_carry ? INFO_REV_M : 0u)
-                    | (rev ? INFO_REV_P : 0u);
+                    | (rev ? INFO_REV_P : 0u) | local_bits(cell);
     if (aa == 1)
       info_lane0 = info;
     if (slot0 >= 0)
@@ -169,7 +178,8 @@ __global__ void __launch_bounds__(256) k_build_patches(BuildArgs a)
     const int lf_n = local_facet(a.cell_facets, cell, fct);
     const int ln_n = local_node(a.cell_nodes, cell, node);
     const uint32_t info = ((uint32_t)fm_carry << INFO_FM_SHIFT) | ((uint32_t)lf_n << INFO_FP_SHIFT)
-                          | ((uint32_t)ln_n << INFO_LN_SHIFT) | (revm_carry ? INFO_REV_M : 0u);
+                          | ((uint32_t)ln_n << INFO_LN_SHIFT) | (revm_carry ? INFO_REV_M : 0u)
+                          | local_bits(cell);
     if (slot0 >= 0)
     {
       a.slot_cell[slot0 + n - 1] = cell;
@@ -226,8 +236,10 @@ k_cell_geometry(int32_t ncells, const double* x, const int32_t* cell_nodes, doub
 void launch_build_patches(const BuildArgs& a, hipStream_t stream)
 {
   const int block = 256;
-  const int grid = (a.nnodes + block - 1) / block;
-  hipLaunchKernelGGL(k_build_patches, dim3(grid), dim3(block), 0, stream, a);
+  const int64_t n = a.inst_node ? a.ninst : (int64_t)a.nnodes;
+  const int grid = (int)((n + block - 1) / block);
+  if (grid > 0)
+    hipLaunchKernelGGL(k_build_patches, dim3(grid), dim3(block), 0, stream, a);
 }
 
 void launch_cell_geometry(int32_t ncells, const double* x, const int32_t* cell_nodes,

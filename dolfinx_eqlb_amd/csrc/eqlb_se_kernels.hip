@@ -90,7 +90,8 @@ int fill_tables_host(int k, int deg, std::vector<double>& out)
 // i.e. the same matrix with the additional load (phi_h, hat_a G) (tensors HG, WG).
 template <int K, int DEG, int P, int SOLVER, int SCATTER, int BLOCK, int MODE = 0>
 __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t block_id, double* lds,
-                                              const bool tables_staged = false)
+                                              const bool tables_staged = false,
+                                              const int64_t lane_index = -1, double* tile_slots = nullptr)
 {
   using Z = Sizes<K, DEG, P>;
   constexpr int KB = Z::KB, NADD = Z::NADD, NDIV = Z::NDIV, NRT = Z::NRT, ND = Z::ND, NQ = Z::NQ;
@@ -123,9 +124,11 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   const int lane = tid & 63;
   const int sub = lane % P;          // lane within the patch group == cell index i
   const int gbase = lane - sub;      // first lane of the group within the wave
-  const int64_t patch_local = (block_id * BLOCK + tid) / P;
+  // lane index within the lane space of the bin (slots are lane-contiguous)
+  const int64_t tl = (lane_index >= 0) ? lane_index : block_id * BLOCK + tid;
+  const int64_t patch_local = tl / P;
   const bool pvalid = patch_local < a.npatch;
-  const int64_t slot = a.slot_offset + patch_local * P + sub;
+  const int64_t slot = a.slot_offset + tl;
   const int64_t patch = a.patch_offset + patch_local;
 
   const int n = pvalid ? (int)a.pn[patch] : 0;
@@ -1061,10 +1064,26 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         cout[3 * K + NDIV + q] = sgn * ul[1 + 2 * KB + q]; // interior unknowns are scaled by sign(detJ),
                                                           // so that the tensors TE/WQ carry no sign
 
-      if constexpr (SCATTER == 0)
+      if constexpr (SCATTER == 2)
+      {
+        // tiled launch: the row goes to the LDS slot of the owned cell; halo lanes drop it
+        const uint32_t loc = info >> INFO_LOCAL_SHIFT;
+        if (loc != 0u)
+        {
+          double* o = tile_slots + ((int64_t)(loc - 1) * 3 + ln) * NRT;
+#pragma unroll
+          for (int e = 0; e < NRT; ++e)
+            o[e] = cout[e];
+        }
+      }
+      else if constexpr (SCATTER == 0)
       {
         // stage the row; the wave stores all rows cooperatively below (or store it directly)
+#ifdef EQLB_EXP_SLOTROW // timing experiment (wrong results): rows of consecutive lanes are contiguous
+        double* o = a.out + (slot % ((int64_t)a.ncells * 3)) * NRT;
+#else
         double* o = EQLB_STAGE_OUT ? stg + lane * NRT : a.out + (((int64_t)r * a.ncells + cell) * 3 + ln) * NRT;
+#endif
 #pragma unroll
         for (int e = 0; e < NRT; ++e)
           o[e] = cout[e];
@@ -1231,6 +1250,111 @@ int launch_ev_patch_fused(int k, const SeArgs& a, const FusedBins& fb, hipStream
     return launch_ev_fused_kd<2, 1>(a, fb, stream);
   if (k == 3)
     return launch_ev_fused_kd<3, 2>(a, fb, stream);
+  return EQLB_ERR_UNSUPPORTED;
+}
+
+// ---- tiled launch: no slot buffer, no reduction pass ----------------------------------------------
+// One workgroup (8 waves) per tile of TC owned cells.  It solves every patch that touches an owned
+// cell (patches on the tile rim are solved by each tile they touch), writes the (cell, vertex) rows
+// of its OWN cells into LDS - every row exactly once, no atomics - and finally adds
+// row(v0) + row(v1) + row(v2) in fixed order to flux_hdiv: bitwise reproducible like the slot path.
+constexpr int tile_cells_c(int k) { return (k >= 3) ? 128 : 256; }
+int tile_cells_of(int k) { return tile_cells_c(k); }
+
+template <int K, int DEG>
+__global__ void __launch_bounds__(512, (K <= 2 ? 4 : 1)) k_se_patch_tiled(const SeArgs a0, const TileArgs ta)
+{
+  extern __shared__ double lds[];
+  using Z = Sizes<K, DEG, 8>;
+  constexpr int NRT = Z::NRT;
+  constexpr int TC = tile_cells_c(K);
+  double* sSlots = lds + Z::NTAB;
+  for (int i = threadIdx.x; i < Z::NTAB; i += 512)
+    lds[i] = a0.tables[Z::NS + i];
+  for (int i = threadIdx.x; i < TC * 3 * NRT; i += 512)
+    sSlots[i] = 0.0;
+  __syncthreads();
+
+  const TileDesc& td = ta.tiles[blockIdx.x];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int NW = 8;
+  int u = wave;
+  SeArgs a = a0;
+#define EQLB_TILE_BIN(B, PP)                                                                        \
+  {                                                                                                 \
+    const int np = td.npatch[B];                                                                    \
+    const int nwb = (np * PP + 63) >> 6;                                                            \
+    a.npatch = np;                                                                                  \
+    a.slot_offset = td.slot_start[B];                                                               \
+    a.patch_offset = td.patch_start[B];                                                             \
+    for (; u < nwb; u += NW)                                                                        \
+      se_patch_body<K, DEG, PP, 1, 2, 64>(a, 0, lds, true, (int64_t)u * 64 + lane, sSlots);         \
+    u -= nwb;                                                                                       \
+  }
+  EQLB_TILE_BIN(0, 4)
+  EQLB_TILE_BIN(1, 8)
+  EQLB_TILE_BIN(2, 16)
+  EQLB_TILE_BIN(3, 32)
+  EQLB_TILE_BIN(4, 64)
+#undef EQLB_TILE_BIN
+  __syncthreads();
+
+  // flush: all reads of the accumulated rows are issued before the first store
+  const int32_t* cells = ta.tile_cells + (int64_t)blockIdx.x * TC;
+  double* x = a0.out + (int64_t)a0.rhs * a0.ncells * NRT;
+  constexpr int NIT = (TC * NRT + 511) / 512;
+  double xv[NIT];
+  int64_t xi[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+  {
+    const int e = it * 512 + threadIdx.x;
+    const int cl = e / NRT, i = e - cl * NRT;
+    const int32_t cell = (e < TC * NRT) ? cells[cl] : -1;
+    xi[it] = (cell >= 0) ? (int64_t)cell * NRT + i : -1;
+    xv[it] = (cell >= 0) ? x[xi[it]] : 0.0;
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+  {
+    const int e = it * 512 + threadIdx.x;
+    const int cl = e / NRT, i = e - cl * NRT;
+    if (xi[it] >= 0)
+    {
+      const double* sl = sSlots + (int64_t)cl * 3 * NRT + i;
+      x[xi[it]] = xv[it] + ((sl[0] + sl[NRT]) + sl[2 * NRT]);
+    }
+  }
+}
+
+template <int K, int DEG>
+static int launch_tiled_kd(const SeArgs& a, const TileArgs& t, hipStream_t stream)
+{
+  using Z = Sizes<K, DEG, 8>;
+  const size_t lds_bytes = sizeof(double) * ((size_t)Z::NTAB + (size_t)t.tc * 3 * Z::NRT);
+  if (lds_bytes > 160 * 1024 || t.tc != tile_cells_c(K))
+    return EQLB_ERR_UNSUPPORTED;
+  auto kern = k_se_patch_tiled<K, DEG>;
+  if (lds_bytes > 64 * 1024)
+  {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+      return EQLB_ERR_DEVICE;
+  }
+  if (t.ntiles == 0)
+    return 0;
+  hipLaunchKernelGGL(kern, dim3((unsigned)t.ntiles), dim3(512), lds_bytes, stream, a, t);
+  return (hipGetLastError() == hipSuccess) ? 0 : EQLB_ERR_DEVICE;
+}
+
+int launch_se_patch_tiled(int k, int deg, const SeArgs& a, const TileArgs& t, hipStream_t stream)
+{
+  if (k == 1 && deg == 0)
+    return launch_tiled_kd<1, 0>(a, t, stream);
+  if (k == 2 && deg == 1)
+    return launch_tiled_kd<2, 1>(a, t, stream);
+  if (k == 3 && deg == 2)
+    return launch_tiled_kd<3, 2>(a, t, stream);
   return EQLB_ERR_UNSUPPORTED;
 }
 

@@ -164,7 +164,8 @@ def make_compatible_data(mesh, k, facet_type, degree_dg=None, seed=20241003, u_e
         vals = np.repeat(adet / 18.0, 9)  # (Pi_0 hat_b, hat_a)_T = |T|/9, |T| = |detJ|/2
     Mg = sp.csr_matrix((vals, (rows, cols)), shape=(nnodes, nnodes))
     Mff = Mg[free][:, free].tocsr()
-    if free.size < 20000:
+    if free.size < 20000 or degree_dg == 0:
+        # (the DG_0 variant of the matrix is too ill-conditioned for Jacobi-CG on large meshes)
         c_free = spla.spsolve(Mff.tocsc(), r[free])
     else:
         d = Mff.diagonal()

@@ -46,6 +46,10 @@ extern "C" {
 #define EQLB_SOLVER_SHUFFLE 1      /* block-tridiagonal elimination in registers, wave shuffles */
 #define EQLB_SCATTER_SLOTS 0       /* per-(cell, vertex) slots + deterministic reduction */
 #define EQLB_SCATTER_ATOMIC 1      /* fp64 global atomic add into the RT coefficient vector */
+#define EQLB_SCATTER_AUTO (-1)     /* default: TILED where it applies (k <= 2, no stress, shuffle solver),
+                                      else SLOTS */
+#define EQLB_SCATTER_TILED 2       /* one workgroup per tile of cells: vertex contributions summed in
+                                      LDS in fixed order, no slot buffer (plain flux equilibration) */
 
 typedef struct eqlb_mesh eqlb_mesh_t;
 typedef struct eqlb_se eqlb_se_t;
@@ -201,6 +205,12 @@ int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, dou
  * P = 4 << b lanes per patch; which = 5: slot-reduction kernel.  Synchronises with the events;
  * 0 if nothing was recorded.  Setting the option again resets the ring. */
 double eqlb_se_last_kernel_ms(const eqlb_se_t* handle, int32_t which);
+
+/* Tiling of the EQLB_SCATTER_TILED launch (built by eqlb_se_set_boundary for plain flux
+ * equilibration): number of tiles, owned cells per tile, patch instances (a patch on a tile rim is
+ * solved once per tile it touches; compare with eqlb_se_num_patches) and lane slots. */
+int eqlb_se_tiling_info(const eqlb_se_t* handle, int64_t* ntiles, int64_t* cells_per_tile,
+                        int64_t* npatch_instances, int64_t* nlane_slots);
 
 /* ---------------------------------------------------------------------------------------------
  * Constrained-minimisation equilibrator (Ern & Vohralik) - replaces

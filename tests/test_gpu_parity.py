@@ -188,3 +188,40 @@ def test_sampled_patches_against_oracle_at_scale(cpp, oracle_mod):
         oracle_mod.se_reconstruct(mesh, k, ft, G[None], f[None], flux_hdiv=ref,
                                   node_range=(int(node), int(node) + 1))
     assert np.abs(x - ref).max() <= RTOL * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+@pytest.mark.parametrize("bc", ["dirichlet", "neumann_lt"])
+def test_tiled_scatter_is_bitwise_the_slot_path(cpp, oracle_mod, k, bc):
+    """EQLB_SCATTER_TILED (one workgroup per tile of cells, vertex rows summed in LDS in fixed
+    order): same bits as slots + reduction; 20x20 crossed squares = several tiles with rims."""
+    mesh, ft, G, f = make_case(20, k, bc)
+    a, _ = _gpu(cpp, mesh, k, ft, G, f, scatter=0)
+    b, eq = _gpu(cpp, mesh, k, ft, G, f, scatter=2)
+    assert np.array_equal(a, b)
+    ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f)
+    assert np.abs(b - ref).max() <= RTOL * np.abs(ref).max()
+    # accumulation into an existing vector
+    c = eq.equilibrate_host(G, f, b.copy())
+    assert np.allclose(c, 2 * b, rtol=1e-14, atol=0)
+
+
+def test_tiled_scatter_multirhs_and_node_mask(cpp):
+    from cases import BCS
+    from dolfinx_eqlb_amd.mesh import create_unit_square
+    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    k = 2
+    mesh = create_unit_square(12, shuffle_seed=3, perturb=0.2)
+    names = ["neumann_lt", "dirichlet", "neumann_bottom"]
+    fts = [facet_types(mesh, BCS[n])[0] for n in names]
+    data = [make_compatible_data(mesh, k, ft[None], seed=11 + i) for i, ft in enumerate(fts)]
+    ft = np.stack(fts)
+    G = np.stack([d[0] for d in data])
+    f = np.stack([d[1] for d in data])
+    a, _ = _gpu(cpp, mesh, k, ft, G, f, scatter=0)
+    b, _ = _gpu(cpp, mesh, k, ft, G, f, scatter=2)
+    assert np.array_equal(a, b)
+    mask = (mesh.x[:, 0] < 0.5).astype(np.uint8)
+    am, _ = _gpu(cpp, mesh, k, ft, G, f, scatter=0, node_mask=mask)
+    bm, _ = _gpu(cpp, mesh, k, ft, G, f, scatter=2, node_mask=mask)
+    assert np.array_equal(am, bm)
