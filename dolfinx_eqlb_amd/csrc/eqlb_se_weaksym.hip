@@ -34,8 +34,12 @@ struct WsSizes
   static constexpr int OFF_R = OFF_C + DCMAX * DCMAX, OFF_W = OFF_R + DCMAX;
   static constexpr int GROUP = OFF_W + 2 * DIMMAX;
   static constexpr int NTAB = Z::NTET + Z::NVT + Z::NVQT; // TE | V | VQ
-  static constexpr int BLOCK = 64;
-  static constexpr int lds_doubles() { return NTAB + (BLOCK / P) * GROUP; }
+  // one wave per block; as many patch groups as fit the 160 KB of LDS (high-valence bins of k = 3
+  // run fewer groups per wave)
+  static constexpr int GROUPS_FIT = (160 * 1024 / 8 - NTAB) / GROUP;
+  static constexpr int GROUPS = (GROUPS_FIT < 1) ? 1 : ((GROUPS_FIT < 64 / P) ? GROUPS_FIT : 64 / P);
+  static constexpr int BLOCK = GROUPS * P;
+  static constexpr int lds_doubles() { return NTAB + GROUPS * GROUP; }
 };
 
 template <int K, int P>
@@ -460,8 +464,10 @@ static int launch_ws_k(int P, const SeArgs& a, hipStream_t stream)
     return launch_ws_t<K, 16>(a, stream);
   case 32:
     return launch_ws_t<K, 32>(a, stream);
+  case 64:
+    return launch_ws_t<K, 64>(a, stream);
   }
-  return EQLB_ERR_UNSUPPORTED; // patches with more than 31 cells: tile does not fit LDS
+  return EQLB_ERR_UNSUPPORTED;
 }
 
 int launch_se_weaksym(int k, int P, const SeArgs& a, hipStream_t stream)

@@ -171,3 +171,40 @@ def create_unit_square(n: int, diagonal: str = "crossed", shuffle_seed=None,
     """
     return create_rectangle(n, n, diagonal=diagonal, shuffle_seed=shuffle_seed, perturb=perturb,
                             perturb_seed=perturb_seed)
+
+
+def create_disk(nsectors: int, nrings: int, shuffle_seed=None, radius: float = 1.0) -> Mesh:
+    """Polar triangulation of a disk: a centre node of valence `nsectors` and `nrings` rings of
+    `nsectors` nodes each (ring-to-ring quads split into two triangles).  Irregular-valence test
+    mesh (adaptive / gmsh meshes of the reference's demos have such nodes); the boundary nodes
+    have 3-cell patches."""
+    ang = 2.0 * np.pi * np.arange(nsectors) / nsectors
+    pts = [np.zeros((1, 2))]
+    for r in range(1, nrings + 1):
+        rad = radius * r / nrings
+        # alternate rings are rotated by half a sector for better-shaped triangles
+        off = 0.5 * (2.0 * np.pi / nsectors) * ((r - 1) % 2)
+        pts.append(rad * np.stack([np.cos(ang + off), np.sin(ang + off)], axis=1))
+    x = np.concatenate(pts)
+
+    def nid(r, i):
+        return 1 + (r - 1) * nsectors + (i % nsectors)
+
+    cells = []
+    for i in range(nsectors):
+        cells.append([0, nid(1, i), nid(1, i + 1)])
+    for r in range(1, nrings):
+        for i in range(nsectors):
+            a, b = nid(r, i), nid(r, i + 1)
+            if (r - 1) % 2 == 0:   # outer ring rotated forward
+                c, d = nid(r + 1, i), nid(r + 1, i + 1)
+                cells.append([a, c, b])
+                cells.append([b, c, d])
+            else:
+                c, d = nid(r + 1, i), nid(r + 1, i + 1)
+                cells.append([a, d, b])
+                cells.append([a, c, d])
+    cells = np.array(cells, dtype=np.int32)
+    if shuffle_seed is not None:
+        cells = _shuffle_local_order(cells, shuffle_seed)
+    return create_mesh(x, cells)
