@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "eqlb_project_dg", "eqlb_se_equilibrate_with_kornconst",
     "eqlb_ev_create", "eqlb_ev_destroy", "eqlb_ev_set_option", "eqlb_ev_set_dofmap",
     "eqlb_ev_num_dofs", "eqlb_ev_set_boundary", "eqlb_ev_equilibrate", "eqlb_ev_num_patches",
-    "eqlb_ev_last_kernel_ms", "eqlb_se_tiling_info",
+    "eqlb_ev_last_kernel_ms", "eqlb_se_tiling_info", "eqlb_se_estimate",
 ]
 
 _lib = None
@@ -325,6 +325,25 @@ def project_dg(dmesh: DeviceMesh, degree: int, qpoints, qweights, qvalues, bs: i
                                  C.c_int32(nq), _hp(qp), _hp(qw), _hp(qv), _hp(out),
                                  C.c_int32(MEM_HOST), None))
     return out
+
+
+def estimate(dmesh: DeviceMesh, k: int, flux_hdiv, flux_dg, rhs_dg):
+    """eqlb_se_estimate on host arrays [nrhs, ...]: returns (cell_div2 [nrhs, ncells],
+    cell_sig2 [nrhs, ncells], facet_jump [nrhs, nfacets])."""
+    m = dmesh.mesh
+    nrt, nd = k * (k + 2), k * (k + 1) // 2
+    x = np.ascontiguousarray(flux_hdiv, dtype=np.float64).reshape(-1, m.ncells * nrt)
+    nrhs = x.shape[0]
+    g = np.ascontiguousarray(flux_dg, dtype=np.float64).reshape(nrhs, -1)
+    f = np.ascontiguousarray(rhs_dg, dtype=np.float64).reshape(nrhs, -1)
+    if g.shape[1] != m.ncells * nd * 2 or f.shape[1] != m.ncells * nd:
+        raise RuntimeError("Equilibration: Input sizes does not match")
+    div2 = np.zeros((nrhs, m.ncells))
+    sig2 = np.zeros((nrhs, m.ncells))
+    jump = np.zeros((nrhs, m.nfacets))
+    _check(lib().eqlb_se_estimate(dmesh._h, C.c_int32(k), C.c_int32(nrhs), _hp(x), _hp(g), _hp(f),
+                                  _hp(div2), _hp(sig2), _hp(jump), C.c_int32(MEM_HOST), None))
+    return div2, sig2, jump
 
 
 def get_reference_table(k, degree_dg, name):

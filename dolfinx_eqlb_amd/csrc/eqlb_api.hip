@@ -975,6 +975,53 @@ int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, dou
   return (int)len;
 }
 
+int eqlb_se_estimate(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const double* flux_hdiv,
+                     const double* flux_dg, const double* rhs_dg, double* cell_div2,
+                     double* cell_sig2, double* facet_jump, int32_t memspace, void* stream_)
+{
+  if (!mesh || !flux_hdiv || !flux_dg || !rhs_dg || nrhs < 1 || k < 1 || k > 3)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_estimate: invalid argument");
+  const eqlb::DeviceMesh& m = mesh->m;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int nrt = k * (k + 2), nd = k * (k + 1) / 2;
+  const size_t n_x = (size_t)nrhs * m.ncells * nrt, n_g = (size_t)nrhs * m.ncells * nd * 2,
+               n_f = (size_t)nrhs * m.ncells * nd;
+  const size_t n_c = (size_t)nrhs * m.ncells, n_e = (size_t)nrhs * m.nfacets;
+  if (memspace == EQLB_MEM_DEVICE)
+  {
+    const int st = eqlb::launch_estimate(m, k, nrhs, flux_hdiv, flux_dg, rhs_dg, cell_div2, cell_sig2,
+                                         facet_jump, stream);
+    return st ? fail(st, "eqlb_se_estimate: kernel launch failed") : EQLB_OK;
+  }
+  if (memspace != EQLB_MEM_HOST)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_estimate: unknown memory space");
+  double *d_x = nullptr, *d_g = nullptr, *d_f = nullptr, *d_d = nullptr, *d_s = nullptr, *d_j = nullptr;
+  int st = upload(&d_x, flux_hdiv, n_x) | upload(&d_g, flux_dg, n_g) | upload(&d_f, rhs_dg, n_f);
+  if (cell_div2)
+    st |= upload<double>(&d_d, nullptr, n_c);
+  if (cell_sig2)
+    st |= upload<double>(&d_s, nullptr, n_c);
+  if (facet_jump)
+    st |= upload<double>(&d_j, nullptr, n_e);
+  int rc = st ? EQLB_ERR_DEVICE : eqlb::launch_estimate(m, k, nrhs, d_x, d_g, d_f, d_d, d_s, d_j, stream);
+  hipError_t e = hipSuccess;
+  if (!rc && cell_div2)
+    e = hipMemcpy(cell_div2, d_d, n_c * sizeof(double), hipMemcpyDeviceToHost);
+  if (!rc && e == hipSuccess && cell_sig2)
+    e = hipMemcpy(cell_sig2, d_s, n_c * sizeof(double), hipMemcpyDeviceToHost);
+  if (!rc && e == hipSuccess && facet_jump)
+    e = hipMemcpy(facet_jump, d_j, n_e * sizeof(double), hipMemcpyDeviceToHost);
+  dfree(d_x);
+  dfree(d_g);
+  dfree(d_f);
+  dfree(d_d);
+  dfree(d_s);
+  dfree(d_j);
+  if (rc || e != hipSuccess)
+    return fail(EQLB_ERR_DEVICE, "eqlb_se_estimate: device error");
+  return EQLB_OK;
+}
+
 // ---- constrained-minimisation (EV) equilibrator ---------------------------------------------------
 int eqlb_ev_create(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, eqlb_ev_t** handle)
 {

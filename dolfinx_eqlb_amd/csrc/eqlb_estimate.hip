@@ -1,0 +1,239 @@
+// Acceptance predicates and estimator quantities on the device - the step right after the
+// equilibration in the reference's workflows: the divergence / jump checks of
+// python/dolfinx_eqlb/eqlb/check_eqlb_conditions.py:183-359 and the cell-wise flux indicator
+// || sigma_eq ||^2_T of demo/poisson/demo_error_estimation.py:52-124 (err_sig for the discontinuous
+// SE flux).  Quadrature-free like the patch kernel: with rho = detJ * (Pi f - div(sigma_eq + G)) in
+// P_{k-1}(ref) and m_q = int rho mono_q,
+//   || Pi f - div(sigma_eq + G) ||^2_T = m^T GMI m / |detJ|,   || sigma_eq ||^2_T = c^T (sum_x g_x S_x) c,
+// and the normal-flux jump of sigma_eq + G on an interior facet from the outward moments of both
+// cells (reversal matrix B when their facet parameters run against each other).
+#include "eqlb_device_common.h"
+#include "eqlb_tables_gen.h"
+
+namespace eqlb
+{
+
+template <int K>
+struct EstTables
+{
+  static constexpr int DEG = K - 1;
+  using R = eqlb_tables::Ref<K, DEG>;
+  static constexpr int NRT = R::NRT, ND = R::ND, NQ = R::NQ;
+  static constexpr int OFF_S = 0, OFF_HG = OFF_S + R::S_SIZE, OFF_DM = OFF_HG + R::HG_SIZE,
+                       OFF_GMI = OFF_DM + R::DM_SIZE, OFF_F0 = OFF_GMI + R::GMI_SIZE,
+                       TOTAL = OFF_F0 + R::F0_SIZE;
+  static void fill(std::vector<double>& t)
+  {
+    t.clear();
+    t.insert(t.end(), R::S, R::S + R::S_SIZE);
+    t.insert(t.end(), R::HG, R::HG + R::HG_SIZE);
+    t.insert(t.end(), R::DM, R::DM + R::DM_SIZE);
+    t.insert(t.end(), R::GMI, R::GMI + R::GMI_SIZE);
+    t.insert(t.end(), R::F0, R::F0 + R::F0_SIZE);
+  }
+};
+
+// one thread per cell: divergence residual and flux norm
+template <int K>
+__global__ void __launch_bounds__(256)
+k_estimate_cells(int32_t ncells, const double* __restrict__ tab, const double* __restrict__ cellJ,
+                 const double* __restrict__ x_eq, const double* __restrict__ flux_dg,
+                 const double* __restrict__ rhs_dg, double* __restrict__ div2, double* __restrict__ sig2)
+{
+  using E = EstTables<K>;
+  constexpr int NRT = E::NRT, ND = E::ND, NQ = E::NQ;
+  extern __shared__ double st[];
+  for (int i = threadIdx.x; i < E::TOTAL; i += 256)
+    st[i] = tab[i];
+  __syncthreads();
+  const int32_t c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncells)
+    return;
+  const double* J = cellJ + 4 * (int64_t)c;
+  const double J00 = J[0], J01 = J[1], J10 = J[2], J11 = J[3];
+  const double detJ = J00 * J11 - J01 * J10, ia = 1.0 / fabs(detJ);
+  const double a00 = J11, a01 = -J01, a10 = -J10, a11 = J00; // adj = detJ * K
+  const double* co = x_eq + (int64_t)c * NRT;
+  double cf[NRT];
+#pragma unroll
+  for (int i = 0; i < NRT; ++i)
+    cf[i] = co[i];
+  if (div2)
+  {
+    double m[NQ];
+    // moments of the reference divergence: q = 0 from the zero-order facet DOFs (facet 1 measures the
+    // outward flux, facets 0 and 2 the inward one), q >= 1 are the div DOFs themselves
+    m[0] = -(-cf[0] + cf[K] - cf[2 * K]);
+#pragma unroll
+    for (int q = 1; q < NQ; ++q)
+      m[q] = -cf[3 * K + q - 1];
+    const double* G = flux_dg + (int64_t)c * ND * 2;
+    const double* f = rhs_dg + (int64_t)c * ND;
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+    {
+      const double gx = G[2 * i], gy = G[2 * i + 1];
+      const double h0 = a00 * gx + a01 * gy, h1 = a10 * gx + a11 * gy, fd = detJ * f[i];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        m[q] += fd * st[E::OFF_HG + i * NQ + q] - h0 * st[E::OFF_DM + (i * 2 + 0) * NQ + q]
+                - h1 * st[E::OFF_DM + (i * 2 + 1) * NQ + q];
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      double r = 0.0;
+#pragma unroll
+      for (int p = 0; p < NQ; ++p)
+        r += st[E::OFF_GMI + q * NQ + p] * m[p];
+      s += m[q] * r;
+    }
+    div2[c] = s * ia;
+  }
+  if (sig2)
+  {
+    const double g0 = (J00 * J00 + J10 * J10) * ia, g1 = (J00 * J01 + J10 * J11) * ia,
+                 g2 = (J01 * J01 + J11 * J11) * ia;
+    double s = 0.0;
+    for (int i = 0; i < NRT; ++i)
+    {
+      double r = 0.0;
+#pragma unroll
+      for (int j = 0; j < NRT; ++j)
+        r += (g0 * st[E::OFF_S + i * NRT + j] + g1 * st[E::OFF_S + (NRT + i) * NRT + j]
+              + g2 * st[E::OFF_S + (2 * NRT + i) * NRT + j])
+             * cf[j];
+      s += cf[i] * r;
+    }
+    // S1 holds phi_i^x phi_j^y + phi_i^y phi_j^x, so c^T S1 c counts the mixed term twice as needed
+    sig2[c] = s;
+  }
+}
+
+// outward moments of (sigma_eq + G) on local facet lf of cell c
+template <int K>
+__device__ __forceinline__ void facet_moments(const double* st, const double* cellJ, const double* x_eq,
+                                              const double* flux_dg, int32_t c, int lf, double* mu)
+{
+  using E = EstTables<K>;
+  constexpr int NRT = E::NRT, ND = E::ND;
+  const double* J = cellJ + 4 * (int64_t)c;
+  const double detJ = J[0] * J[3] - J[1] * J[2];
+  const double sgn = (detJ > 0.0) ? 1.0 : -1.0, pf = (lf == 1) ? sgn : -sgn;
+  const double a00 = J[3], a01 = -J[1], a10 = -J[2], a11 = J[0];
+  const double nx = (lf == 2) ? 0.0 : -1.0, ny = (lf == 0) ? -1.0 : ((lf == 1) ? 0.0 : 1.0);
+  const double nu0 = a00 * nx + a10 * ny, nu1 = a01 * nx + a11 * ny; // adj^T N_f
+#pragma unroll
+  for (int j = 0; j < K; ++j)
+    mu[j] = x_eq[(int64_t)c * NRT + lf * K + j];
+  const double* G = flux_dg + (int64_t)c * ND * 2;
+#pragma unroll
+  for (int i = 0; i < ND; ++i)
+  {
+    const double gn = G[2 * i] * nu0 + G[2 * i + 1] * nu1;
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+      mu[j] += st[E::OFF_F0 + (lf * ND + i) * K + j] * gn;
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j)
+    mu[j] *= pf;
+}
+
+// one thread per facet: max_j |moment_j of the normal-flux jump| (0 on boundary facets)
+template <int K>
+__global__ void __launch_bounds__(256)
+k_estimate_facets(int32_t nfacets, const double* __restrict__ tab, const double* __restrict__ cellJ,
+                  const int32_t* __restrict__ cell_facets, const uint8_t* __restrict__ facet_perm,
+                  const int32_t* __restrict__ facet_cells_off, const int32_t* __restrict__ facet_cells,
+                  const double* __restrict__ x_eq, const double* __restrict__ flux_dg,
+                  double* __restrict__ jump)
+{
+  using E = EstTables<K>;
+  extern __shared__ double st[];
+  for (int i = threadIdx.x; i < E::TOTAL; i += 256)
+    st[i] = tab[i];
+  __syncthreads();
+  const int32_t fct = blockIdx.x * 256 + threadIdx.x;
+  if (fct >= nfacets)
+    return;
+  const int32_t o = facet_cells_off[fct];
+  if (facet_cells_off[fct + 1] - o < 2)
+  {
+    jump[fct] = 0.0;
+    return;
+  }
+  const int32_t c0 = facet_cells[o], c1 = facet_cells[o + 1];
+  int l0 = 0, l1 = 0;
+#pragma unroll
+  for (int l = 1; l < 3; ++l)
+  {
+    if (cell_facets[(int64_t)c0 * 3 + l] == fct)
+      l0 = l;
+    if (cell_facets[(int64_t)c1 * 3 + l] == fct)
+      l1 = l;
+  }
+  double m0[K], m1[K];
+  facet_moments<K>(st, cellJ, x_eq, flux_dg, c0, l0, m0);
+  facet_moments<K>(st, cellJ, x_eq, flux_dg, c1, l1, m1);
+  const bool rev = facet_perm[(int64_t)c0 * 3 + l0] != facet_perm[(int64_t)c1 * 3 + l1];
+  double worst = 0.0;
+#pragma unroll
+  for (int j = 0; j < K; ++j)
+  {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+      t += (rev ? bcoef(j, i) : ((i == j) ? 1.0 : 0.0)) * m1[i];
+    worst = fmax(worst, fabs(m0[j] + t));
+  }
+  jump[fct] = worst;
+}
+
+template <int K>
+static int launch_estimate_k(const DeviceMesh& m, int nrhs, const double* x_eq, const double* flux_dg,
+                             const double* rhs_dg, double* div2, double* sig2, double* jump,
+                             hipStream_t stream)
+{
+  using E = EstTables<K>;
+  std::vector<double> t;
+  E::fill(t);
+  double* d_t = nullptr;
+  if (hipMalloc(&d_t, t.size() * sizeof(double)) != hipSuccess)
+    return EQLB_ERR_DEVICE;
+  hipError_t e = hipMemcpyAsync(d_t, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, stream);
+  const size_t lds = t.size() * sizeof(double);
+  const int64_t nx = (int64_t)m.ncells * E::NRT, ng = (int64_t)m.ncells * E::ND * 2, nf = (int64_t)m.ncells * E::ND;
+  for (int r = 0; r < nrhs && e == hipSuccess; ++r)
+  {
+    if (div2 || sig2)
+      hipLaunchKernelGGL(k_estimate_cells<K>, dim3((m.ncells + 255) / 256), dim3(256), lds, stream, m.ncells,
+                         d_t, m.cellJ, x_eq + r * nx, flux_dg + r * ng, rhs_dg + r * nf,
+                         div2 ? div2 + (int64_t)r * m.ncells : nullptr,
+                         sig2 ? sig2 + (int64_t)r * m.ncells : nullptr);
+    if (jump)
+      hipLaunchKernelGGL(k_estimate_facets<K>, dim3((m.nfacets + 255) / 256), dim3(256), lds, stream,
+                         m.nfacets, d_t, m.cellJ, m.cell_facets, m.facet_perm, m.facet_cells_off,
+                         m.facet_cells, x_eq + r * nx, flux_dg + r * ng, jump + (int64_t)r * m.nfacets);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(stream); // the table buffer is freed below
+  (void)hipFree(d_t);
+  return (e == hipSuccess) ? 0 : EQLB_ERR_DEVICE;
+}
+
+int launch_estimate(const DeviceMesh& m, int k, int nrhs, const double* x_eq, const double* flux_dg,
+                    const double* rhs_dg, double* div2, double* sig2, double* jump, hipStream_t stream)
+{
+  if (k == 1)
+    return launch_estimate_k<1>(m, nrhs, x_eq, flux_dg, rhs_dg, div2, sig2, jump, stream);
+  if (k == 2)
+    return launch_estimate_k<2>(m, nrhs, x_eq, flux_dg, rhs_dg, div2, sig2, jump, stream);
+  if (k == 3)
+    return launch_estimate_k<3>(m, nrhs, x_eq, flux_dg, rhs_dg, div2, sig2, jump, stream);
+  return EQLB_ERR_UNSUPPORTED;
+}
+
+} // namespace eqlb

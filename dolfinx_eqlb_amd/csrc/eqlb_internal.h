@@ -152,6 +152,8 @@ void launch_project_dg(int64_t ncells, int nd, int nq, int bs, const double* Pm,
 void launch_korn(const DeviceMesh& m, const int64_t* node_slot, const int64_t* node_patch,
                  const int32_t* slot_cell, const uint32_t* slot_info, const uint8_t* pn,
                  const uint8_t* pflag, double* cks, double* korn, hipStream_t stream);
+int launch_estimate(const DeviceMesh& m, int k, int nrhs, const double* x_eq, const double* flux_dg,
+                    const double* rhs_dg, double* div2, double* sig2, double* jump, hipStream_t stream);
 size_t table_doubles(int k, int deg);
 int fill_tables_host(int k, int deg, std::vector<double>& out);
 

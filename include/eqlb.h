@@ -206,6 +206,19 @@ int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, dou
  * 0 if nothing was recorded.  Setting the option again resets the ring. */
 double eqlb_se_last_kernel_ms(const eqlb_se_t* handle, int32_t which);
 
+/* Acceptance predicates and estimator quantities of a semi-explicit result, on the device - the
+ * step after the equilibration in the reference's workflows:
+ *   cell_div2  [nrhs][ncells]  || Pi f - div(sigma_eq + G) ||^2_L2(T)   (divergence condition,
+ *                              python/dolfinx_eqlb/eqlb/check_eqlb_conditions.py:183-291)
+ *   cell_sig2  [nrhs][ncells]  || sigma_eq ||^2_L2(T)                   (flux indicator err_sig of
+ *                              demo/poisson/demo_error_estimation.py:93-100 for the SE flux)
+ *   facet_jump [nrhs][nfacets] max_j | j-th moment of [(sigma_eq + G).n] | on interior facets, 0 on
+ *                              boundary facets (H(div) conformity, check_eqlb_conditions.py:294-359)
+ * Any output may be NULL.  Arrays in the layouts of eqlb_se_equilibrate; memspace as there. */
+int eqlb_se_estimate(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const double* flux_hdiv,
+                     const double* flux_dg, const double* rhs_dg, double* cell_div2,
+                     double* cell_sig2, double* facet_jump, int32_t memspace, void* stream);
+
 /* Tiling of the EQLB_SCATTER_TILED launch (built by eqlb_se_set_boundary for plain flux
  * equilibration): number of tiles, owned cells per tile, patch instances (a patch on a tile rim is
  * solved once per tile it touches; compare with eqlb_se_num_patches) and lane slots. */

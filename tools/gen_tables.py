@@ -109,8 +109,18 @@ def tables_exact(k, deg):
                         for c in range(2):
                             WG[ci][h][d][c] = sum(Q[r][h] * d0[r] * WGF[ln][idx[r]][d][c]
                                                   for r in range(ny))
+    # acceptance / estimator step on the device (eqlb_estimate.hip): moments of grad psi_i against
+    # the monomials, inverse Gram matrix of the monomials, facet moments of psi_i (no hat)
+    nq_ = len(monos)
+    DM = [[[P.integrate_triangle(P.mul(d(dg.basis[i]), P.monomial(l, m))) for (l, m) in monos]
+           for d in (P.ddx, P.ddy)] for i in range(nd)]
+    gram = [[P.integrate_triangle(P.mul(P.monomial(*monos[a]), P.monomial(*monos[b])))
+             for b in range(nq_)] for a in range(nq_)]
+    GMI = P.solve_exact(gram, [[Fraction(int(a == b)) for b in range(nq_)] for a in range(nq_)])
+    F0 = [[[sum(F[f][n][i][j] for n in range(3)) for j in range(k)] for i in range(nd)]
+          for f in range(3)]
     return dict(k=k, deg=deg, nrt=nrt, nd=nd, nq=len(monos), S=S, F=F, H=H, D=D, B=B, TE=TE, WQ=WQ,
-                V=V, VQ=VQ, HB=HB, HG=HG, WGF=WGF, WG=WG)
+                V=V, VQ=VQ, HB=HB, HG=HG, WGF=WGF, WG=WG, DM=DM, GMI=GMI, F0=F0)
 
 
 def _local_maps(k, B, fm, fp, rev):
@@ -228,7 +238,8 @@ def tables_float(k, deg):
     import numpy as np
     t = tables_exact(k, deg)
     out = dict(k=k, deg=deg, nrt=t["nrt"], nd=t["nd"], nq=t["nq"])
-    for name in ("S", "F", "H", "D", "B", "TE", "WQ", "V", "VQ", "HB", "HG", "WGF", "WG"):
+    for name in ("S", "F", "H", "D", "B", "TE", "WQ", "V", "VQ", "HB", "HG", "WGF", "WG", "DM", "GMI",
+                 "F0"):
         def shape(x):
             return (len(x),) + shape(x[0]) if isinstance(x, list) else ()
         out[name] = np.array([float(v) for v in _flat(t[name])]).reshape(shape(t[name]))
@@ -271,6 +282,9 @@ def emit(path):
         arr("HB", (3, 3, k, k), t["HB"])
         arr("HG", (nd, nq), t["HG"])
         arr("WG", (18, nh_, nd, 2), t["WG"])
+        arr("DM", (nd, 2, nq), t["DM"])
+        arr("GMI", (nq, nq), t["GMI"])
+        arr("F0", (3, nd, k), t["F0"])
         lines.append("};")
         lines.append("")
     # Lagrange P_d (Basix numbering, equispaced): monomial coefficients and inverse mass matrix
