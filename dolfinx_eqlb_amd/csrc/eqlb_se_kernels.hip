@@ -696,18 +696,26 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       const int prevl = (sub > 0) ? sub - 1 : nn - 1;
       const bool has_prevcell = pvalid && sub < nf && (sub > 0 || interior_geo);
 
-      // (a) masked copy of the element system (identity rows of se/assembly.hpp:209-251)
-      double T[NH][NH], Lv[NH];
-#pragma unroll
-      for (int h = 0; h < NH; ++h)
+      // (a) element system with the rows/columns of fixed (flux-BC) unknowns cleared (identity rows
+      // of se/assembly.hpp:209-251); patches with flux BCs are rare, so the masking sits behind a
+      // branch that whole waves skip
+      double(&T)[NH][NH] = Te;
+      double(&Lv)[NH] = Le;
+      if (d_fixed || fx_m || fx_p)
       {
-        const bool fh = (h == 0) ? d_fixed : ((h <= KB) ? fx_m : ((h <= 2 * KB) ? fx_p : false));
-        Lv[h] = fh ? 0.0 : Le[h];
 #pragma unroll
-        for (int g = 0; g < NH; ++g)
+        for (int h = 0; h < NH; ++h)
         {
-          const bool fg = (g == 0) ? d_fixed : ((g <= KB) ? fx_m : ((g <= 2 * KB) ? fx_p : false));
-          T[h][g] = (fh || fg) ? 0.0 : Te[h][g];
+          const bool fh = (h == 0) ? d_fixed : ((h <= KB) ? fx_m : ((h <= 2 * KB) ? fx_p : false));
+          if (fh)
+            Lv[h] = 0.0;
+#pragma unroll
+          for (int g = 0; g < NH; ++g)
+          {
+            const bool fg = (g == 0) ? d_fixed : ((g <= KB) ? fx_m : ((g <= 2 * KB) ? fx_p : false));
+            if (fh || fg)
+              T[h][g] = 0.0;
+          }
         }
       }
       // (b) static condensation of the cell-interior unknown (k >= 3)
@@ -1075,6 +1083,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
           for (int e = 0; e < NRT; ++e)
             o[e] = cout[e];
         }
+        (void)0;
       }
       else if constexpr (SCATTER == 0)
       {
