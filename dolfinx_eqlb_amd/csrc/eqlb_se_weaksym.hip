@@ -32,7 +32,11 @@ struct WsSizes
   // per patch: A0, A1 (packed lower) | Y [DIMMAX][2*NPMAX] | C [DCMAX][DCMAX] | rhs_c [DCMAX] | w [2][DIMMAX]
   static constexpr int OFF_A1 = TRI, OFF_Y = 2 * TRI, OFF_C = OFF_Y + DIMMAX * 2 * NPMAX;
   static constexpr int OFF_R = OFF_C + DCMAX * DCMAX, OFF_W = OFF_R + DCMAX;
-  static constexpr int GROUP = OFF_W + 2 * DIMMAX;
+  static constexpr int OFF_D = OFF_W + 2 * DIMMAX; // 1 / L_ii of both factors
+  static constexpr int GROUP = OFF_D + 2 * DIMMAX;
+  // register variants of the serial phases (columns of Y, rows of the Schur system) where they fit
+  static constexpr bool REG_Y = DIMMAX <= 32;
+  static constexpr bool REG_LU = P <= 16;
   static constexpr int NTAB = Z::NTET + Z::NVT + Z::NVQT; // TE | V | VQ
   // one wave per block; as many patch groups as fit the 160 KB of LDS (high-valence bins of k = 3
   // run fewer groups per wave)
@@ -114,6 +118,7 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
   double* Cg = Ag + W::OFF_C;
   double* Rg = Ag + W::OFF_R;
   double* Wg = Ag + W::OFF_W;
+  double* Dg = Ag + W::OFF_D;
 
   // ---- element quantities ----
   double Te[NH][NH];
@@ -280,9 +285,11 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
       const double ajj = Ak[tri(j, j)];
       if (!(ajj > 0.0))
         status_local = 1;
-      const double ljj = sqrt(ajj > 0.0 ? ajj : 1.0);
-      const double inv = 1.0 / ljj;
+      const double inv = rsqrt_d(ajj > 0.0 ? ajj : 1.0);
+      const double ljj = (ajj > 0.0 ? ajj : 1.0) * inv;
       wave_sync();
+      if (sub == 0)
+        Dg[k * W::DIMMAX + j] = inv;
       for (int i = j + sub; i < dim; i += P)
         Ak[tri(i, j)] = (i == j) ? ljj : Ak[tri(i, j)] * inv;
       wave_sync();
@@ -299,14 +306,43 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
   for (int col = sub; col < 2 * npnt; col += P)
   {
     const int k = col / npnt, c = col - k * npnt;
-    const double* Ak = Ag + ((requires_bcs && k == 1) ? W::OFF_A1 : 0);
+    const int ko = (requires_bcs && k == 1) ? 1 : 0;
+    const double* Ak = Ag + ko * W::OFF_A1;
+    const double* Dk = Dg + ko * W::DIMMAX;
     double* y = Yg + k * NPMAX + c;
-    for (int i = 0; i < dim; ++i)
+    if constexpr (W::REG_Y)
     {
-      double t = y[i * LDY];
-      for (int q = 0; q < i; ++q)
-        t -= Ak[tri(i, q)] * y[q * LDY];
-      y[i * LDY] = t / Ak[tri(i, i)];
+      // the column lives in registers: no LDS round trip inside the dependent chain
+      double yr[W::DIMMAX];
+#pragma unroll
+      for (int i = 0; i < W::DIMMAX; ++i)
+        yr[i] = (i < dim) ? y[i * LDY] : 0.0;
+#pragma unroll
+      for (int i = 0; i < W::DIMMAX; ++i)
+      {
+        if (i < dim)
+        {
+          double t = yr[i];
+#pragma unroll
+          for (int q = 0; q < i; ++q)
+            t -= Ak[tri(i, q)] * yr[q];
+          yr[i] = t * Dk[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < W::DIMMAX; ++i)
+        if (i < dim)
+          y[i * LDY] = yr[i];
+    }
+    else
+    {
+      for (int i = 0; i < dim; ++i)
+      {
+        double t = y[i * LDY];
+        for (int q = 0; q < i; ++q)
+          t -= Ak[tri(i, q)] * y[q * LDY];
+        y[i * LDY] = t * Dk[i];
+      }
     }
   }
   wave_sync();
@@ -321,8 +357,101 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
     Cg[r * DCMAX + c] -= t;
   }
   wave_sync();
-  // ---- dense LU with partial pivoting (one lane per patch; <= (P+3)^2 entries) ----
-  if (sub == 0 && pvalid)
+  // ---- dense LU with partial pivoting of the (npnt [+1])^2 Schur system ----
+  if constexpr (W::REG_LU)
+  {
+    // rows r = sub and r = sub + P of [C | rhs] in registers; per column: cross-lane arg-max of the
+    // pivot candidates (first maximum, like a serial partial-pivot LU), broadcast of the pivot row,
+    // elimination in all rows not used yet (implicit row permutation), then back substitution
+    const int gb = (tid & 63) - sub;
+    double r0[DCMAX + 1], r1[DCMAX + 1];
+#pragma unroll
+    for (int j = 0; j < DCMAX; ++j)
+    {
+      r0[j] = (sub < dim_c && j < dim_c) ? Cg[sub * DCMAX + j] : 0.0;
+      r1[j] = (sub + P < dim_c && j < dim_c) ? Cg[(sub + P) * DCMAX + j] : 0.0;
+    }
+    r0[DCMAX] = (sub < dim_c) ? Rg[sub] : 0.0;
+    r1[DCMAX] = (sub + P < dim_c) ? Rg[sub + P] : 0.0;
+    bool free0 = sub < dim_c, free1 = sub + P < dim_c;
+    int prow[DCMAX]; // pivot row of column c
+#pragma unroll
+    for (int c = 0; c < DCMAX; ++c)
+    {
+      prow[c] = 0;
+      if (c < dim_c)
+      {
+        double bv = free0 ? fabs(r0[c]) : -1.0;
+        int br = sub;
+        const double v1 = free1 ? fabs(r1[c]) : -1.0;
+        if (v1 > bv)
+        {
+          bv = v1;
+          br = sub + P;
+        }
+#pragma unroll
+        for (int off = 1; off < P; off <<= 1)
+        {
+          const double ov = __shfl(bv, gb + (sub ^ off), 64);
+          const int orow = __shfl(br, gb + (sub ^ off), 64);
+          if (ov > bv || (ov == bv && orow < br))
+          {
+            bv = ov;
+            br = orow;
+          }
+        }
+        if (!(bv > 0.0))
+        {
+          status_local = pvalid ? 1 : status_local;
+          bv = 1.0;
+        }
+        prow[c] = br;
+        const int owner = gb + (br % P);
+        const bool second = br >= P;
+        double pr[DCMAX + 1];
+#pragma unroll
+        for (int j = c; j <= DCMAX; ++j)
+          pr[j] = __shfl(second ? r1[j] : r0[j], owner, 64);
+        const double ip = rcp_d((pr[c] != 0.0) ? pr[c] : 1.0);
+        if (br == sub)
+          free0 = false;
+        if (br == sub + P)
+          free1 = false;
+        const double f0 = free0 ? r0[c] * ip : 0.0, f1 = free1 ? r1[c] * ip : 0.0;
+#pragma unroll
+        for (int j = c; j <= DCMAX; ++j)
+        {
+          r0[j] -= f0 * pr[j];
+          r1[j] -= f1 * pr[j];
+        }
+      }
+    }
+    // back substitution: gamma[c] from the pivot row of column c, broadcast to the group
+    double gam[DCMAX];
+#pragma unroll
+    for (int c = DCMAX - 1; c >= 0; --c)
+    {
+      gam[c] = 0.0;
+      if (c < dim_c)
+      {
+        const int br = prow[c];
+        const bool second = br >= P;
+        double t = second ? r1[DCMAX] : r0[DCMAX];
+#pragma unroll
+        for (int j = c + 1; j < DCMAX; ++j)
+          t -= (second ? r1[j] : r0[j]) * gam[j];
+        const double d = second ? r1[c] : r0[c];
+        t *= rcp_d((d != 0.0) ? d : 1.0);
+        gam[c] = __shfl(t, gb + (br % P), 64);
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int c = 0; c < DCMAX; ++c)
+      if (sub == 0 && pvalid && c < dim_c)
+        Rg[c] = gam[c];
+  }
+  else if (sub == 0 && pvalid)
   {
     for (int c = 0; c < dim_c; ++c)
     {
@@ -385,14 +514,16 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
   if (sub < 2 && pvalid)
   {
     const int k = sub;
-    const double* Ak = Ag + ((requires_bcs && k == 1) ? W::OFF_A1 : 0);
+    const int ko = (requires_bcs && k == 1) ? 1 : 0;
+    const double* Ak = Ag + ko * W::OFF_A1;
+    const double* Dk = Dg + ko * W::DIMMAX;
     double* w = Wg + k * W::DIMMAX;
     for (int i = dim - 1; i >= 0; --i)
     {
       double t = w[i];
       for (int q = i + 1; q < dim; ++q)
         t -= Ak[tri(q, i)] * w[q];
-      w[i] = t / Ak[tri(i, i)];
+      w[i] = t * Dk[i];
     }
   }
   wave_sync();
