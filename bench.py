@@ -174,8 +174,10 @@ def main():
     bytes_sweep = compulsory_bytes_per_cell(k, 1, args.ev) * part.ncells_owned
     if fused:  # one launch does the whole sweep
         alg_bytes = float(bytes_sweep)
-        kname = f"k_ev_patch_fused<K={k}>" if args.ev else (
-            f"k_se_patch_tiled<K={k}>" if args.scatter == 2 else f"k_se_patch_fused<K={k}>")
+        if args.ev:  # library default: tiled launch for k <= 2
+            kname = f"k_se_patch_tiled<K={k},EV>" if k <= 2 else f"k_ev_patch_fused<K={k}>"
+        else:
+            kname = f"k_se_patch_tiled<K={k}>" if args.scatter == 2 else f"k_se_patch_fused<K={k}>"
         kernels_ms = {kname: bins_ms[0]}
     else:      # share of the sweep done by the dominant bin's launch
         alg_bytes = bytes_sweep * ncells_bin[dom] / total_pc
@@ -204,7 +206,7 @@ def main():
             "patches_per_gpu": npatch_local, "cells_per_gpu": int(part.ncells_owned),
             "nrhs": nrhs, "weak_symmetry": bool(args.stress), "partition": "node-ownership strips" if world > 1 else "none",
             "solver": eq_solver_name(None if args.ev else args.solver),
-            "scatter": eq_scatter_name(None if args.ev else args.scatter),
+            "scatter": ("tiled" if k <= 2 else "slots") if args.ev else eq_scatter_name(args.scatter),
         },
         "roofline": {
             "bound": "hbm",

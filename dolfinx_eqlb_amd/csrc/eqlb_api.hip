@@ -65,6 +65,7 @@ void free_boundary(eqlb_se* h)
   dfree(h->slots); // re-zeroed on the next call (node_mask may have changed)
   dfree(h->t_tiles);
   dfree(h->t_tile_cells);
+  dfree(h->t_facet_owner);
   dfree(h->t_slot_cell);
   dfree(h->t_slot_info);
   dfree(h->t_pn);
@@ -528,11 +529,20 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
   eqlb::launch_build_patches(a, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
-  if (h->mode == 0 && !h->stress)
+  if (!h->stress && (h->mode == 0 || h->k <= 2))
   {
     const int stt = build_tiles(h, node_bin, a);
     if (stt)
       return stt;
+    if (h->mode == 1)
+    {
+      const int64_t ne = (int64_t)h->ntiles * h->tile_tc * 3;
+      if (upload<int32_t>(&h->t_facet_owner, nullptr, (size_t)std::max<int64_t>(ne, 1)))
+        return EQLB_ERR_DEVICE;
+      eqlb::launch_tile_facet_owner(m, ne, h->t_tile_cells, h->t_facet_owner, nullptr);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipDeviceSynchronize());
+    }
   }
   h->boundary_set = true;
   return EQLB_OK;
@@ -676,7 +686,7 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
   // equilibration, shuffle solver), else slots + reduction
   int scatter_eff = h->scatter;
   if (scatter_eff == EQLB_SCATTER_AUTO)
-    scatter_eff = (h->mode == 0 && !h->stress && h->k <= 2 && h->solver == EQLB_SOLVER_SHUFFLE && h->ntiles > 0)
+    scatter_eff = (!h->stress && h->k <= 2 && h->solver == EQLB_SOLVER_SHUFFLE && h->ntiles > 0)
                       ? EQLB_SCATTER_TILED
                       : EQLB_SCATTER_SLOTS;
   h->scatter_last = scatter_eff;
@@ -684,8 +694,8 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
   // EV mode writes conforming DOFs unless the broken layout is requested
   const bool ev_conf = h->mode == 1 && h->ev_output == 0;
   const size_t n_x = ev_conf ? (size_t)h->nrhs * h->ev_ndofs : n_slot;
-  if (h->mode == 1 && (scatter_eff != EQLB_SCATTER_SLOTS || h->solver != EQLB_SOLVER_SHUFFLE))
-    return fail(EQLB_ERR_UNSUPPORTED, "EV equilibration runs with the shuffle solver and slot scatter");
+  if (h->mode == 1 && (scatter_eff == EQLB_SCATTER_ATOMIC || h->solver != EQLB_SOLVER_SHUFFLE))
+    return fail(EQLB_ERR_UNSUPPORTED, "EV equilibration runs with the shuffle solver (tiled or slot scatter)");
 
   const double *d_g = flux_dg, *d_f = rhs_dg;
   double* d_x = flux_hdiv;
@@ -745,10 +755,11 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
   const bool tiled = scatter_eff == EQLB_SCATTER_TILED;
   if (tiled)
   {
-    if (h->mode != 0 || h->stress || h->solver != EQLB_SOLVER_SHUFFLE || h->ntiles == 0)
+    if (h->stress || h->solver != EQLB_SOLVER_SHUFFLE || h->ntiles == 0)
       return fail(EQLB_ERR_UNSUPPORTED,
-                  "the tiled scatter is available for plain flux equilibration with the shuffle solver");
-    eqlb::TileArgs ta{h->t_tiles, h->t_tile_cells, h->ntiles, h->tile_tc};
+                  "the tiled scatter is available for k <= 2 flux equilibration with the shuffle solver");
+    eqlb::TileArgs ta{h->t_tiles, h->t_tile_cells, h->ntiles, h->tile_tc,
+                      ev_conf ? h->t_facet_owner : nullptr, h->ev_cell_dofs, h->ev_ndofs, m.nfacets};
     a.slot_cell = h->t_slot_cell;
     a.slot_info = h->t_slot_info;
     a.pn = h->t_pn;
@@ -760,7 +771,7 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
       a.rhs = r;
       if (evs && r == 0)
         HIP_TRY(hipEventRecord(evs[0], stream));
-      const int st = eqlb::launch_se_patch_tiled(h->k, h->deg, a, ta, stream);
+      const int st = eqlb::launch_se_patch_tiled(h->k, h->deg, h->mode, a, ta, stream);
       if (st)
         return fail(st, "tiled patch kernel launch failed (k=%d)", h->k);
     }
@@ -1032,7 +1043,6 @@ int eqlb_ev_create(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, eqlb_ev_t** handl
   if (st)
     return st;
   se->mode = 1;
-  se->scatter = EQLB_SCATTER_SLOTS;
   se->ev_ndofs = (int64_t)mesh->m.nfacets * k + (int64_t)mesh->m.ncells * (k * k - k);
   eqlb_ev* h = new eqlb_ev();
   h->se = se;
@@ -1066,7 +1076,7 @@ int eqlb_ev_set_option(eqlb_ev_t* h, const char* key, int32_t value)
     dfree(h->se->d_rhs_dg);
     return EQLB_OK;
   }
-  if (!strcmp(key, "timing"))
+  if (!strcmp(key, "timing") || !strcmp(key, "scatter"))
     return eqlb_se_set_option(h->se, key, value);
   return fail(EQLB_ERR_INVALID_ARGUMENT, "unknown option '%s'", key);
 }

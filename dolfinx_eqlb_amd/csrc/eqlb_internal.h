@@ -93,6 +93,11 @@ struct TileArgs
   const TileDesc* tiles;
   const int32_t* tile_cells; // [ntiles][tc] owned cells (-1: padding)
   int32_t ntiles, tc;
+  // EV flush to the conforming DOFs (nullptr: broken layout)
+  const int32_t* facet_owner; // [ntiles][tc][3] 2 * facet + reversal bit, or -1
+  const int32_t* cell_dofs;   // caller's dofmap or nullptr (default numbering)
+  int64_t ndofs;
+  int32_t nfacets;
 };
 
 struct BuildArgs
@@ -132,7 +137,9 @@ int launch_se_patch(int k, int deg, int P, int solver, int scatter, const SeArgs
                     hipStream_t stream);
 int launch_se_patch_fused(int k, int deg, int scatter, const SeArgs& a, const FusedBins& fb,
                           hipStream_t stream);
-int launch_se_patch_tiled(int k, int deg, const SeArgs& a, const TileArgs& t, hipStream_t stream);
+int launch_se_patch_tiled(int k, int deg, int mode, const SeArgs& a, const TileArgs& t, hipStream_t stream);
+void launch_tile_facet_owner(const DeviceMesh& m, int64_t n, const int32_t* tile_cells, int32_t* code,
+                             hipStream_t stream);
 int tile_cells_of(int k);
 int launch_se_weaksym(int k, int P, const SeArgs& a, hipStream_t stream);
 int launch_ev_patch_fused(int k, const SeArgs& a, const FusedBins& fb, hipStream_t stream);
@@ -198,7 +205,7 @@ struct eqlb_se
   int32_t ntiles = 0, tile_tc = 0;
   int64_t t_nslots = 0, t_npatch = 0;
   eqlb::TileDesc* t_tiles = nullptr;
-  int32_t *t_tile_cells = nullptr, *t_slot_cell = nullptr;
+  int32_t *t_tile_cells = nullptr, *t_slot_cell = nullptr, *t_facet_owner = nullptr;
   uint32_t* t_slot_info = nullptr;
   uint8_t *t_pn = nullptr, *t_pflag = nullptr;
   double* slots = nullptr;          // [nrhs][ncells][3][nrt]

@@ -1270,16 +1270,53 @@ int launch_ev_patch_fused(int k, const SeArgs& a, const FusedBins& fb, hipStream
 constexpr int tile_cells_c(int k) { return (k >= 3) ? 128 : 256; }
 int tile_cells_of(int k) { return tile_cells_c(k); }
 
-template <int K, int DEG>
+// facet-owner table of the EV flush: for the owned cell cl of a tile and its local facet lf the
+// code 2 * facet + reversal bit if the cell is the FIRST cell of the facet (it writes the facet's
+// conforming DOFs), else -1
+__global__ void __launch_bounds__(256)
+k_tile_facet_owner(int64_t n, const int32_t* __restrict__ tile_cells, const int32_t* __restrict__ cell_facets,
+                   const int32_t* __restrict__ facet_cells_off, const int32_t* __restrict__ facet_cells,
+                   const uint8_t* __restrict__ facet_perm, int32_t* __restrict__ code)
+{
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n)
+    return;
+  const int32_t c = tile_cells[e / 3];
+  const int lf = (int)(e % 3);
+  int32_t v = -1;
+  if (c >= 0)
+  {
+    const int32_t fct = cell_facets[(int64_t)c * 3 + lf];
+    if (facet_cells[facet_cells_off[fct]] == c)
+      v = 2 * fct + (facet_perm[(int64_t)c * 3 + lf] ? 1 : 0);
+  }
+  code[e] = v;
+}
+
+void launch_tile_facet_owner(const DeviceMesh& m, int64_t n, const int32_t* tile_cells, int32_t* code,
+                             hipStream_t stream)
+{
+  if (n > 0)
+    hipLaunchKernelGGL(k_tile_facet_owner, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n,
+                       tile_cells, m.cell_facets, m.facet_cells_off, m.facet_cells, m.facet_perm, code);
+}
+
+// MODE 0: semi-explicit flux, flux_hdiv in the broken layout.  MODE 1: EV patch problems; flush to
+// the conforming DOFs (ta.facet_owner != nullptr) or to the broken layout ("output" = 1).
+template <int K, int DEG, int MODE>
 __global__ void __launch_bounds__(512, (K <= 2 ? 4 : 1)) k_se_patch_tiled(const SeArgs a0, const TileArgs ta)
 {
   extern __shared__ double lds[];
   using Z = Sizes<K, DEG, 8>;
   constexpr int NRT = Z::NRT;
   constexpr int TC = tile_cells_c(K);
-  double* sSlots = lds + Z::NTAB;
+  constexpr int NTABM = Z::NTAB + (MODE ? Z::NEV : 0);
+  double* sSlots = lds + NTABM;
   for (int i = threadIdx.x; i < Z::NTAB; i += 512)
     lds[i] = a0.tables[Z::NS + i];
+  if constexpr (MODE == 1)
+    for (int i = threadIdx.x; i < Z::NEV; i += 512)
+      lds[Z::NTAB + i] = a0.tables[Z::OFF_HG + i];
   for (int i = threadIdx.x; i < TC * 3 * NRT; i += 512)
     sSlots[i] = 0.0;
   __syncthreads();
@@ -1297,7 +1334,7 @@ __global__ void __launch_bounds__(512, (K <= 2 ? 4 : 1)) k_se_patch_tiled(const 
     a.slot_offset = td.slot_start[B];                                                               \
     a.patch_offset = td.patch_start[B];                                                             \
     for (; u < nwb; u += NW)                                                                        \
-      se_patch_body<K, DEG, PP, 1, 2, 64>(a, 0, lds, true, (int64_t)u * 64 + lane, sSlots);         \
+      se_patch_body<K, DEG, PP, 1, 2, 64, MODE>(a, 0, lds, true, (int64_t)u * 64 + lane, sSlots);   \
     u -= nwb;                                                                                       \
   }
   EQLB_TILE_BIN(0, 4)
@@ -1308,8 +1345,55 @@ __global__ void __launch_bounds__(512, (K <= 2 ? 4 : 1)) k_se_patch_tiled(const 
 #undef EQLB_TILE_BIN
   __syncthreads();
 
-  // flush: all reads of the accumulated rows are issued before the first store
   const int32_t* cells = ta.tile_cells + (int64_t)blockIdx.x * TC;
+  if (MODE == 1 && ta.facet_owner != nullptr)
+  {
+    // conforming DOFs (ev/solve_patch.hpp:223-227): facet DOFs by the first cell of the facet,
+    // mapped to the global facet frame (T_f = -I / B), interior DOFs by their cell
+    constexpr int NI = K * K - K;
+    double* x = a0.out + (int64_t)a0.rhs * ta.ndofs;
+    const int32_t* own = ta.facet_owner + (int64_t)blockIdx.x * TC * 3;
+    for (int e = threadIdx.x; e < TC * 3; e += 512)
+    {
+      const int32_t code = own[e];
+      if (code < 0)
+        continue;
+      const int cl = e / 3, lf = e - 3 * cl;
+      const int32_t cell = cells[cl], fct = code >> 1;
+      const bool rev = (code & 1) != 0;
+      const double* sl = sSlots + (int64_t)cl * 3 * NRT + lf * K;
+      double v[K];
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+        v[j] = (sl[j] + sl[NRT + j]) + sl[2 * NRT + j];
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+      {
+        double g = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+          g += (rev ? bcoef(j, i) : ((i == j) ? -1.0 : 0.0)) * v[i];
+        const int64_t dof = ta.cell_dofs ? (int64_t)ta.cell_dofs[(int64_t)cell * NRT + lf * K + j]
+                                         : (int64_t)fct * K + j;
+        x[dof] += g;
+      }
+    }
+    if constexpr (NI > 0)
+      for (int e = threadIdx.x; e < TC * NI; e += 512)
+      {
+        const int cl = e / NI, i = e - cl * NI;
+        const int32_t cell = cells[cl];
+        if (cell < 0)
+          continue;
+        const double* sl = sSlots + (int64_t)cl * 3 * NRT + 3 * K + i;
+        const int64_t dof = ta.cell_dofs ? (int64_t)ta.cell_dofs[(int64_t)cell * NRT + 3 * K + i]
+                                         : (int64_t)ta.nfacets * K + (int64_t)cell * NI + i;
+        x[dof] += (sl[0] + sl[NRT]) + sl[2 * NRT];
+      }
+    return;
+  }
+
+  // flush: all reads of the accumulated rows are issued before the first store
   double* x = a0.out + (int64_t)a0.rhs * a0.ncells * NRT;
   constexpr int NIT = (TC * NRT + 511) / 512;
   double xv[NIT];
@@ -1336,14 +1420,15 @@ __global__ void __launch_bounds__(512, (K <= 2 ? 4 : 1)) k_se_patch_tiled(const 
   }
 }
 
-template <int K, int DEG>
+template <int K, int DEG, int MODE>
 static int launch_tiled_kd(const SeArgs& a, const TileArgs& t, hipStream_t stream)
 {
   using Z = Sizes<K, DEG, 8>;
-  const size_t lds_bytes = sizeof(double) * ((size_t)Z::NTAB + (size_t)t.tc * 3 * Z::NRT);
+  const size_t lds_bytes
+      = sizeof(double) * ((size_t)Z::NTAB + (MODE ? (size_t)Z::NEV : 0) + (size_t)t.tc * 3 * Z::NRT);
   if (lds_bytes > 160 * 1024 || t.tc != tile_cells_c(K))
     return EQLB_ERR_UNSUPPORTED;
-  auto kern = k_se_patch_tiled<K, DEG>;
+  auto kern = k_se_patch_tiled<K, DEG, MODE>;
   if (lds_bytes > 64 * 1024)
   {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1356,14 +1441,22 @@ static int launch_tiled_kd(const SeArgs& a, const TileArgs& t, hipStream_t strea
   return (hipGetLastError() == hipSuccess) ? 0 : EQLB_ERR_DEVICE;
 }
 
-int launch_se_patch_tiled(int k, int deg, const SeArgs& a, const TileArgs& t, hipStream_t stream)
+int launch_se_patch_tiled(int k, int deg, int mode, const SeArgs& a, const TileArgs& t, hipStream_t stream)
 {
+  if (mode == 1)
+  {
+    if (k == 1)
+      return launch_tiled_kd<1, 0, 1>(a, t, stream);
+    if (k == 2)
+      return launch_tiled_kd<2, 1, 1>(a, t, stream);
+    return EQLB_ERR_UNSUPPORTED;
+  }
   if (k == 1 && deg == 0)
-    return launch_tiled_kd<1, 0>(a, t, stream);
+    return launch_tiled_kd<1, 0, 0>(a, t, stream);
   if (k == 2 && deg == 1)
-    return launch_tiled_kd<2, 1>(a, t, stream);
+    return launch_tiled_kd<2, 1, 0>(a, t, stream);
   if (k == 3 && deg == 2)
-    return launch_tiled_kd<3, 2>(a, t, stream);
+    return launch_tiled_kd<3, 2, 0>(a, t, stream);
   return EQLB_ERR_UNSUPPORTED;
 }
 

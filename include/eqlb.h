@@ -250,7 +250,8 @@ int eqlb_ev_create(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, eqlb_ev_t** handl
 void eqlb_ev_destroy(eqlb_ev_t* handle);
 
 /* "output": 0 conforming DOFs (default), 1 broken hierarchic RT_k layout [ncells*k(k+2)] as
- * eqlb_se_equilibrate writes it; "timing": as eqlb_se_set_option. */
+ * eqlb_se_equilibrate writes it; "timing", "scatter" (EQLB_SCATTER_AUTO / _SLOTS / _TILED): as
+ * eqlb_se_set_option. */
 int eqlb_ev_set_option(eqlb_ev_t* handle, const char* key, int32_t value);
 
 /* cell_dofs [ncells][k(k+2)] host array (NULL restores the default numbering), ndofs = size of the

@@ -126,3 +126,30 @@ def test_ev_golden(name):
     eq = cpp.ConstrainedMinEquilibrator(cpp.DeviceMesh(mesh), k, G.shape[0])
     eq.set_boundary(ft)
     assert _close(eq.equilibrate_host(G, f), expected)
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_ev_tiled_is_bitwise_the_slot_path(oracle_mod, k):
+    """EV on the tiled launch (default for k <= 2): conforming flush by facet owner."""
+    from dolfinx_eqlb_amd import cpp
+    mesh, ft, G, f = make_case(20, k, "neumann_lt")
+    cd, nd = conforming_dofmap(mesh, k)
+    dm = cpp.DeviceMesh(mesh)
+    out = {}
+    for sc in (0, 2):
+        eq = cpp.ConstrainedMinEquilibrator(dm, k, 1)
+        eq.set_option("scatter", sc)
+        eq.set_boundary(ft)
+        out[sc] = eq.equilibrate_host(G, f)
+        eq.set_option("output", 1)
+        out[sc, "broken"] = eq.equilibrate_host(G, f)
+    assert np.array_equal(out[0], out[2])
+    assert np.array_equal(out[0, "broken"], out[2, "broken"])
+    ref = oracle_mod.ev_reconstruct(mesh, k, ft, G, f, cd, nd)
+    assert _close(out[2], ref)
+    # custom dofmap on the tiled path
+    perm = np.random.default_rng(5).permutation(nd).astype(np.int32)
+    eqp = cpp.ConstrainedMinEquilibrator(dm, k, 1, cell_dofs=perm[cd], ndofs=nd)
+    eqp.set_option("scatter", 2)
+    eqp.set_boundary(ft)
+    assert _close(eqp.equilibrate_host(G, f)[0][perm], ref[0])
