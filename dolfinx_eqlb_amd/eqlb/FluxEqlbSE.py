@@ -55,6 +55,15 @@ class FluxEqlbSE:
         degree_dg = {1: 0, 3: 1, 6: 2, 10: 3}.get(nd)
         if degree_dg is None or nd * msh.ncells != self.list_rhs[0].size:
             raise RuntimeError("Equilibration: Input sizes does not match")
+        if degree_dg > degree_flux - 1:  # se/reconstruction.hpp:363-373
+            raise RuntimeError("Equilibration: Wrong polynomial degree of the projected RHS")
+        if degree_dg < degree_flux - 1:
+            # lower-degree data: embedded exactly into DG_{k-1}, the space the kernels work in
+            from ..lsolver import embed_dg
+            self.list_rhs = [embed_dg(r, msh.ncells, degree_dg, degree_flux - 1) for r in self.list_rhs]
+            self.list_proj_flux = [embed_dg(g, msh.ncells, degree_dg, degree_flux - 1, bs=2)
+                                   for g in self.list_proj_flux]
+            degree_dg = degree_flux - 1
         self.degree_dg = degree_dg
         self.device_mesh = device_mesh if device_mesh is not None else cpp.DeviceMesh(msh)
         self._eq = cpp.SemiExplicitEquilibrator(self.device_mesh, degree_flux, self.n_fluxes,

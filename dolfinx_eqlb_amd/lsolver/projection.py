@@ -41,3 +41,19 @@ def local_projection(dmesh: "cpp.DeviceMesh", degree: int, data: typing.List[typ
         vals.append(v.reshape(mesh.ncells, qw.size, bs))
     out = cpp.project_dg(dmesh, degree, qp, qw, np.stack(vals), bs)
     return [out[i] for i in range(len(data))]
+
+
+def embed_dg(values, ncells: int, degree_from: int, degree_to: int, bs: int = 1):
+    """Exact embedding DG_{degree_from} -> DG_{degree_to} (degree_to >= degree_from) of nodal
+    values [ncells*nd_from*bs]: the reference accepts projected data of any degree <= k-1
+    (se/reconstruction.hpp:363-373); the device kernels take DG_{k-1}, which contains them."""
+    import numpy as np
+
+    from ..elmtlib.lagrange import Lagrange
+    if degree_to < degree_from:
+        raise RuntimeError("Equilibration: Wrong polynomial degree of the projected RHS")
+    lo, hi = Lagrange(degree_from), Lagrange(degree_to)
+    nodes = np.array([[float(a), float(b)] for a, b in hi.nodes])
+    E = lo.tabulate(nodes)[0]  # [nd_to, nd_from]
+    v = np.asarray(values, dtype=np.float64).reshape(ncells, lo.ndofs, bs)
+    return np.ascontiguousarray(np.einsum("ij,cjb->cib", E, v).reshape(-1))
