@@ -131,10 +131,13 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   const int64_t slot = a.slot_offset + tl;
   const int64_t patch = a.patch_offset + patch_local;
 
+  // the unused lanes of a patch group hold cell = -1 (the SoA is initialised so): the descriptor
+  // loads do not depend on each other and the gathers of J, G, f wait for ONE load latency
   const int n = pvalid ? (int)a.pn[patch] : 0;
-  const bool active = pvalid && sub < n;
-  const int32_t cell = active ? a.slot_cell[slot] : 0;
-  const uint32_t info = active ? a.slot_info[slot] : 0u;
+  const int32_t cell_raw = pvalid ? a.slot_cell[slot] : -1;
+  const uint32_t info = pvalid ? a.slot_info[slot] : 0u;
+  const bool active = cell_raw >= 0;
+  const int32_t cell = active ? cell_raw : 0;
   const int fm = (info >> INFO_FM_SHIFT) & 3, fp = (info >> INFO_FP_SHIFT) & 3;
   const int ln = (info >> INFO_LN_SHIFT) & 3;
   const bool rev_m = (info & INFO_REV_M) != 0, rev_p = (info & INFO_REV_P) != 0;
