@@ -36,6 +36,9 @@ struct WsSizes
   static constexpr int GROUP = OFF_D + 2 * DIMMAX;
   // register variants of the serial phases (columns of Y, rows of the Schur system) where they fit
   static constexpr bool REG_Y = DIMMAX <= 32;
+  // small patches (k = 2, up to 8 cells): every lane keeps its own copy of the Cholesky factor in
+  // registers - the factorisation and all substitutions run without LDS round trips or syncs
+  static constexpr bool REG_A = DIMMAX <= 9;
   static constexpr bool REG_LU = P <= 16;
   static constexpr int NTAB = Z::NTET + Z::NVT + Z::NVQT; // TE | V | VQ
   // one wave per block; as many patch groups as fit the 160 KB of LDS (high-valence bins of k = 3
@@ -275,33 +278,67 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
 
   int status_local = 0;
   // ---- Cholesky of A (both rows if masked) ----
-  for (int k = 0; k < 2; ++k)
+  constexpr int NLR = W::REG_A ? W::TRI : 1, NDR = W::REG_A ? W::DIMMAX : 1;
+  double Lr[NLR], Dr[NDR];
+  const bool use_reg = W::REG_A && !requires_bcs; // uniform within a patch group
+  if constexpr (W::REG_A)
   {
-    if (k == 1 && !requires_bcs)
-      break;
-    double* Ak = Ag + k * W::OFF_A1;
-    for (int j = 0; j < dim; ++j)
+    if (use_reg)
     {
-      const double ajj = Ak[tri(j, j)];
-      if (!(ajj > 0.0))
-        status_local = 1;
-      const double inv = rsqrt_d(ajj > 0.0 ? ajj : 1.0);
-      const double ljj = (ajj > 0.0 ? ajj : 1.0) * inv;
-      wave_sync();
-      if (sub == 0)
-        Dg[k * W::DIMMAX + j] = inv;
-      for (int i = j + sub; i < dim; i += P)
-        Ak[tri(i, j)] = (i == j) ? ljj : Ak[tri(i, j)] * inv;
-      wave_sync();
-      for (int i = j + 1 + sub; i < dim; i += P)
+      // rows beyond dim are padded with the identity
+#pragma unroll
+      for (int i = 0; i < W::DIMMAX; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j)
+          Lr[tri(i, j)] = (i < dim) ? Ag[tri(i, j)] : ((i == j) ? 1.0 : 0.0);
+#pragma unroll
+      for (int j = 0; j < W::DIMMAX; ++j)
       {
-        const double lij = Ak[tri(i, j)];
-        for (int kk = j + 1; kk <= i; ++kk)
-          Ak[tri(i, kk)] -= lij * Ak[tri(kk, j)];
+        const double ajj = Lr[tri(j, j)];
+        if (!(ajj > 0.0))
+          status_local = 1;
+        const double inv = rsqrt_d(ajj > 0.0 ? ajj : 1.0);
+        Lr[tri(j, j)] = (ajj > 0.0 ? ajj : 1.0) * inv;
+        Dr[j] = inv;
+#pragma unroll
+        for (int i = j + 1; i < W::DIMMAX; ++i)
+          Lr[tri(i, j)] *= inv;
+#pragma unroll
+        for (int i = j + 1; i < W::DIMMAX; ++i)
+#pragma unroll
+          for (int kk = j + 1; kk <= i; ++kk)
+            Lr[tri(i, kk)] -= Lr[tri(i, j)] * Lr[tri(kk, j)];
       }
-      wave_sync();
     }
   }
+  if (!use_reg)
+    for (int k = 0; k < 2; ++k)
+    {
+      if (k == 1 && !requires_bcs)
+        break;
+      double* Ak = Ag + k * W::OFF_A1;
+      for (int j = 0; j < dim; ++j)
+      {
+        const double ajj = Ak[tri(j, j)];
+        if (!(ajj > 0.0))
+          status_local = 1;
+        const double inv = rsqrt_d(ajj > 0.0 ? ajj : 1.0);
+        const double ljj = (ajj > 0.0 ? ajj : 1.0) * inv;
+        wave_sync();
+        if (sub == 0)
+          Dg[k * W::DIMMAX + j] = inv;
+        for (int i = j + sub; i < dim; i += P)
+          Ak[tri(i, j)] = (i == j) ? ljj : Ak[tri(i, j)] * inv;
+        wave_sync();
+        for (int i = j + 1 + sub; i < dim; i += P)
+        {
+          const double lij = Ak[tri(i, j)];
+          for (int kk = j + 1; kk <= i; ++kk)
+            Ak[tri(i, kk)] -= lij * Ak[tri(kk, j)];
+        }
+        wave_sync();
+      }
+    }
   // ---- Y_k = L_k^-1 B_k: every lane forward-substitutes whole columns ----
   for (int col = sub; col < 2 * npnt; col += P)
   {
@@ -317,16 +354,36 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
 #pragma unroll
       for (int i = 0; i < W::DIMMAX; ++i)
         yr[i] = (i < dim) ? y[i * LDY] : 0.0;
-#pragma unroll
-      for (int i = 0; i < W::DIMMAX; ++i)
+      bool done = false;
+      if constexpr (W::REG_A)
       {
-        if (i < dim)
+        if (use_reg)
         {
-          double t = yr[i];
 #pragma unroll
-          for (int q = 0; q < i; ++q)
-            t -= Ak[tri(i, q)] * yr[q];
-          yr[i] = t * Dk[i];
+          for (int i = 0; i < W::DIMMAX; ++i)
+          {
+            double t = yr[i];
+#pragma unroll
+            for (int q = 0; q < i; ++q)
+              t -= Lr[tri(i, q)] * yr[q];
+            yr[i] = t * Dr[i];
+          }
+          done = true;
+        }
+      }
+      if (!done)
+      {
+#pragma unroll
+        for (int i = 0; i < W::DIMMAX; ++i)
+        {
+          if (i < dim)
+          {
+            double t = yr[i];
+#pragma unroll
+            for (int q = 0; q < i; ++q)
+              t -= Ak[tri(i, q)] * yr[q];
+            yr[i] = t * Dk[i];
+          }
         }
       }
 #pragma unroll
@@ -511,7 +568,34 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
     Wg[k * W::DIMMAX + i] = t;
   }
   wave_sync();
-  if (sub < 2 && pvalid)
+  if (W::REG_A && use_reg)
+  {
+    if constexpr (W::REG_A)
+    {
+      if (sub < 2 && pvalid)
+      {
+        double* w = Wg + sub * W::DIMMAX;
+        double wr[W::DIMMAX];
+#pragma unroll
+        for (int i = 0; i < W::DIMMAX; ++i)
+          wr[i] = (i < dim) ? w[i] : 0.0;
+#pragma unroll
+        for (int i = W::DIMMAX - 1; i >= 0; --i)
+        {
+          double t = wr[i];
+#pragma unroll
+          for (int q = i + 1; q < W::DIMMAX; ++q)
+            t -= Lr[tri(q, i)] * wr[q];
+          wr[i] = t * Dr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < W::DIMMAX; ++i)
+          if (i < dim)
+            w[i] = wr[i];
+      }
+    }
+  }
+  else if (sub < 2 && pvalid)
   {
     const int k = sub;
     const int ko = (requires_bcs && k == 1) ? 1 : 0;
