@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = [
     "eqlb_ev_create", "eqlb_ev_destroy", "eqlb_ev_set_option", "eqlb_ev_set_dofmap",
     "eqlb_ev_num_dofs", "eqlb_ev_set_boundary", "eqlb_ev_equilibrate", "eqlb_ev_num_patches",
     "eqlb_ev_last_kernel_ms", "eqlb_se_tiling_info", "eqlb_se_estimate",
+    "eqlb_halo_pack", "eqlb_halo_unpack_add",
 ]
 
 _lib = None
@@ -344,6 +345,19 @@ def estimate(dmesh: DeviceMesh, k: int, flux_hdiv, flux_dg, rhs_dg):
     _check(lib().eqlb_se_estimate(dmesh._h, C.c_int32(k), C.c_int32(nrhs), _hp(x), _hp(g), _hp(f),
                                   _hp(div2), _hp(sig2), _hp(jump), C.c_int32(MEM_HOST), None))
     return div2, sig2, jump
+
+
+def halo_pack(x_ptr, cells_ptr, buf_ptr, nrhs, nlist, nrt, ncells, clear=True, stream=0):
+    """eqlb_halo_pack on raw device pointers (asynchronous on `stream`)."""
+    _check(lib().eqlb_halo_pack(C.c_int32(nrhs), C.c_int32(nlist), C.c_int32(nrt), C.c_int64(ncells),
+                                C.c_void_p(cells_ptr), C.c_void_p(x_ptr), C.c_void_p(buf_ptr),
+                                C.c_int32(int(clear)), C.c_void_p(stream)))
+
+
+def halo_unpack_add(x_ptr, cells_ptr, buf_ptr, nrhs, nlist, nrt, ncells, stream=0):
+    _check(lib().eqlb_halo_unpack_add(C.c_int32(nrhs), C.c_int32(nlist), C.c_int32(nrt),
+                                      C.c_int64(ncells), C.c_void_p(cells_ptr), C.c_void_p(x_ptr),
+                                      C.c_void_p(buf_ptr), C.c_void_p(stream)))
 
 
 def get_reference_table(k, degree_dg, name):

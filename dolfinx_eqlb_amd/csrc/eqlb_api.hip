@@ -1033,6 +1033,25 @@ int eqlb_se_estimate(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const double* f
   return EQLB_OK;
 }
 
+int eqlb_halo_pack(int32_t nrhs, int32_t nlist, int32_t nrt, int64_t ncells, const int64_t* cells,
+                   double* x, double* buf, int32_t clear, void* stream)
+{
+  if (nrhs < 0 || nlist < 0 || nrt < 1 || (nlist > 0 && (!cells || !x || !buf)))
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_halo_pack: invalid argument");
+  eqlb::launch_halo_pack(nrhs, nlist, nrt, ncells, cells, x, buf, clear, reinterpret_cast<hipStream_t>(stream));
+  return (hipGetLastError() == hipSuccess) ? EQLB_OK : fail(EQLB_ERR_DEVICE, "eqlb_halo_pack: launch failed");
+}
+
+int eqlb_halo_unpack_add(int32_t nrhs, int32_t nlist, int32_t nrt, int64_t ncells, const int64_t* cells,
+                         double* x, const double* buf, void* stream)
+{
+  if (nrhs < 0 || nlist < 0 || nrt < 1 || (nlist > 0 && (!cells || !x || !buf)))
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_halo_unpack_add: invalid argument");
+  eqlb::launch_halo_unpack_add(nrhs, nlist, nrt, ncells, cells, x, buf, reinterpret_cast<hipStream_t>(stream));
+  return (hipGetLastError() == hipSuccess) ? EQLB_OK
+                                           : fail(EQLB_ERR_DEVICE, "eqlb_halo_unpack_add: launch failed");
+}
+
 // ---- constrained-minimisation (EV) equilibrator ---------------------------------------------------
 int eqlb_ev_create(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, eqlb_ev_t** handle)
 {

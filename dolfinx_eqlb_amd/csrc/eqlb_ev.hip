@@ -141,4 +141,55 @@ void launch_ev_reduce(const DeviceMesh& m, int k, int nrhs, const int32_t* cell_
                        m.facet_perm, m.facet_cells_off, m.facet_cells, cell_dofs, ndofs, slots, x);
 }
 
+// ---- halo rows of the multi-GPU decomposition -----------------------------------------------------
+// pack: buf[r][i][:] = x[r][cells[i]][:], then the ghost rows are cleared (their content moves to the
+// owner); unpack: x[r][cells[i]][:] += buf[r][i][:].  One launch each instead of a chain of
+// framework indexing kernels in the timed step.
+__global__ void __launch_bounds__(256)
+k_halo_pack(int64_t n, int32_t ncells_list, int32_t nrt, int64_t ncells, const int64_t* __restrict__ cells,
+            double* __restrict__ x, double* __restrict__ buf, int clear)
+{
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n)
+    return;
+  const int64_t per = (int64_t)ncells_list * nrt;
+  const int64_t r = e / per, q = e - r * per;
+  const int64_t i = q / nrt, j = q - i * nrt;
+  double* px = x + (r * ncells + cells[i]) * nrt + j;
+  buf[e] = *px;
+  if (clear)
+    *px = 0.0;
+}
+
+__global__ void __launch_bounds__(256)
+k_halo_unpack_add(int64_t n, int32_t ncells_list, int32_t nrt, int64_t ncells,
+                  const int64_t* __restrict__ cells, double* __restrict__ x, const double* __restrict__ buf)
+{
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n)
+    return;
+  const int64_t per = (int64_t)ncells_list * nrt;
+  const int64_t r = e / per, q = e - r * per;
+  const int64_t i = q / nrt, j = q - i * nrt;
+  x[(r * ncells + cells[i]) * nrt + j] += buf[e];
+}
+
+void launch_halo_pack(int nrhs, int32_t nlist, int32_t nrt, int64_t ncells, const int64_t* cells, double* x,
+                      double* buf, int clear, hipStream_t stream)
+{
+  const int64_t n = (int64_t)nrhs * nlist * nrt;
+  if (n > 0)
+    hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, nlist, nrt,
+                       ncells, cells, x, buf, clear);
+}
+
+void launch_halo_unpack_add(int nrhs, int32_t nlist, int32_t nrt, int64_t ncells, const int64_t* cells,
+                            double* x, const double* buf, hipStream_t stream)
+{
+  const int64_t n = (int64_t)nrhs * nlist * nrt;
+  if (n > 0)
+    hipLaunchKernelGGL(k_halo_unpack_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, nlist,
+                       nrt, ncells, cells, x, buf);
+}
+
 } // namespace eqlb

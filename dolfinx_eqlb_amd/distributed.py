@@ -97,21 +97,36 @@ class HaloExchange:
 
     def reduce(self, x):
         """x: [nrhs * ncells * nrt] tensor; adds the neighbour's partial sums to the owned rows
-        and clears the ghost rows (their content now lives on the owner)."""
+        and clears the ghost rows (their content now lives on the owner).  Device tensors use the
+        two halo kernels of libeqlb_amd.so (one launch each) around the RCCL send/recv; CPU tensors
+        (gloo tests) use plain indexing."""
+        import torch
         import torch.distributed as dist
         part = self.part
         xv = x.view(self.nrhs, part.mesh.ncells, self.nrt)
+        on_gpu = x.is_cuda
+        ns, nr = int(part.send_cells.size), int(part.recv_cells.size)
+        stream = torch.cuda.current_stream().cuda_stream if on_gpu else 0
         ops = []
-        if part.send_cells.size:
-            self.send_buf.copy_(xv[:, self.send_idx, :])
+        if ns:
+            if on_gpu:
+                from . import cpp
+                cpp.halo_pack(x.data_ptr(), self.send_idx.data_ptr(), self.send_buf.data_ptr(),
+                              self.nrhs, ns, self.nrt, part.mesh.ncells, True, stream)
+            else:
+                self.send_buf.copy_(xv[:, self.send_idx, :])
+                xv[:, self.send_idx, :] = 0.0
             ops.append(dist.P2POp(dist.isend, self.send_buf, part.rank + 1))
-        if part.recv_cells.size:
+        if nr:
             ops.append(dist.P2POp(dist.irecv, self.recv_buf, part.rank - 1))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
-        if part.recv_cells.size:
-            xv[:, self.recv_idx, :] += self.recv_buf
-        if part.send_cells.size:
-            xv[:, self.send_idx, :] = 0.0
+        if nr:
+            if on_gpu:
+                from . import cpp
+                cpp.halo_unpack_add(x.data_ptr(), self.recv_idx.data_ptr(), self.recv_buf.data_ptr(),
+                                    self.nrhs, nr, self.nrt, part.mesh.ncells, stream)
+            else:
+                xv[:, self.recv_idx, :] += self.recv_buf
         return x

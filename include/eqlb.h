@@ -219,6 +219,18 @@ int eqlb_se_estimate(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const double* f
                      const double* flux_dg, const double* rhs_dg, double* cell_div2,
                      double* cell_sig2, double* facet_jump, int32_t memspace, void* stream);
 
+/* Multi-GPU decomposition by node ownership (the reference has no distributed
+ * equilibration, se/reconstruction.hpp:90 loops the owned nodes only): after the local sweep the
+ * partial sums of the ghost-cell rows are sent to the owning rank and added there.  DEVICE pointers:
+ *   eqlb_halo_pack        buf[r][i][:] = x[r][cells[i]][:]  (i < nlist), rows cleared if clear != 0
+ *   eqlb_halo_unpack_add  x[r][cells[i]][:] += buf[r][i][:]
+ * x [nrhs][ncells][nrt], cells [nlist] int64, buf [nrhs][nlist][nrt]; asynchronous on `stream`.  The
+ * transport between the two calls is the caller's (RCCL send/recv in dolfinx_eqlb_amd/distributed.py). */
+int eqlb_halo_pack(int32_t nrhs, int32_t nlist, int32_t nrt, int64_t ncells, const int64_t* cells,
+                   double* x, double* buf, int32_t clear, void* stream);
+int eqlb_halo_unpack_add(int32_t nrhs, int32_t nlist, int32_t nrt, int64_t ncells, const int64_t* cells,
+                         double* x, const double* buf, void* stream);
+
 /* Tiling of the EQLB_SCATTER_TILED launch (built by eqlb_se_set_boundary for plain flux
  * equilibration): number of tiles, owned cells per tile, patch instances (a patch on a tile rim is
  * solved once per tile it touches; compare with eqlb_se_num_patches) and lane slots. */
