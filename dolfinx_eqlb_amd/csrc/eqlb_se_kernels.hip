@@ -1270,7 +1270,11 @@ int launch_ev_patch_fused(int k, const SeArgs& a, const FusedBins& fb, hipStream
 // cell (patches on the tile rim are solved by each tile they touch), writes the (cell, vertex) rows
 // of its OWN cells into LDS - every row exactly once, no atomics - and finally adds
 // row(v0) + row(v1) + row(v2) in fixed order to flux_hdiv: bitwise reproducible like the slot path.
-constexpr int tile_cells_c(int k) { return (k >= 3) ? 128 : 256; }
+#ifndef EQLB_TILE_THREADS
+#define EQLB_TILE_THREADS 512
+#endif
+constexpr int TILE_THREADS = EQLB_TILE_THREADS; // 8 waves own 256 cells, 16 waves 512 (k <= 2)
+constexpr int tile_cells_c(int k) { return ((k >= 3) ? 128 : 256) * (TILE_THREADS / 512); }
 int tile_cells_of(int k) { return tile_cells_c(k); }
 
 // facet-owner table of the EV flush: for the owned cell cl of a tile and its local facet lf the
@@ -1307,7 +1311,7 @@ void launch_tile_facet_owner(const DeviceMesh& m, int64_t n, const int32_t* tile
 // MODE 0: semi-explicit flux, flux_hdiv in the broken layout.  MODE 1: EV patch problems; flush to
 // the conforming DOFs (ta.facet_owner != nullptr) or to the broken layout ("output" = 1).
 template <int K, int DEG, int MODE>
-__global__ void __launch_bounds__(512, (K <= 2 ? 4 : 1)) k_se_patch_tiled(const SeArgs a0, const TileArgs ta)
+__global__ void __launch_bounds__(TILE_THREADS, (K <= 2 ? 4 : 1)) k_se_patch_tiled(const SeArgs a0, const TileArgs ta)
 {
   extern __shared__ double lds[];
   using Z = Sizes<K, DEG, 8>;
@@ -1315,18 +1319,18 @@ __global__ void __launch_bounds__(512, (K <= 2 ? 4 : 1)) k_se_patch_tiled(const 
   constexpr int TC = tile_cells_c(K);
   constexpr int NTABM = Z::NTAB + (MODE ? Z::NEV : 0);
   double* sSlots = lds + NTABM;
-  for (int i = threadIdx.x; i < Z::NTAB; i += 512)
+  for (int i = threadIdx.x; i < Z::NTAB; i += TILE_THREADS)
     lds[i] = a0.tables[Z::NS + i];
   if constexpr (MODE == 1)
-    for (int i = threadIdx.x; i < Z::NEV; i += 512)
+    for (int i = threadIdx.x; i < Z::NEV; i += TILE_THREADS)
       lds[Z::NTAB + i] = a0.tables[Z::OFF_HG + i];
-  for (int i = threadIdx.x; i < TC * 3 * NRT; i += 512)
+  for (int i = threadIdx.x; i < TC * 3 * NRT; i += TILE_THREADS)
     sSlots[i] = 0.0;
   __syncthreads();
 
   const TileDesc& td = ta.tiles[blockIdx.x];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  constexpr int NW = 8;
+  constexpr int NW = TILE_THREADS / 64;
   int u = wave;
   SeArgs a = a0;
 #define EQLB_TILE_BIN(B, PP)                                                                        \
@@ -1356,7 +1360,7 @@ __global__ void __launch_bounds__(512, (K <= 2 ? 4 : 1)) k_se_patch_tiled(const 
     constexpr int NI = K * K - K;
     double* x = a0.out + (int64_t)a0.rhs * ta.ndofs;
     const int32_t* own = ta.facet_owner + (int64_t)blockIdx.x * TC * 3;
-    for (int e = threadIdx.x; e < TC * 3; e += 512)
+    for (int e = threadIdx.x; e < TC * 3; e += TILE_THREADS)
     {
       const int32_t code = own[e];
       if (code < 0)
@@ -1382,7 +1386,7 @@ __global__ void __launch_bounds__(512, (K <= 2 ? 4 : 1)) k_se_patch_tiled(const 
       }
     }
     if constexpr (NI > 0)
-      for (int e = threadIdx.x; e < TC * NI; e += 512)
+      for (int e = threadIdx.x; e < TC * NI; e += TILE_THREADS)
       {
         const int cl = e / NI, i = e - cl * NI;
         const int32_t cell = cells[cl];
@@ -1398,13 +1402,13 @@ __global__ void __launch_bounds__(512, (K <= 2 ? 4 : 1)) k_se_patch_tiled(const 
 
   // flush: all reads of the accumulated rows are issued before the first store
   double* x = a0.out + (int64_t)a0.rhs * a0.ncells * NRT;
-  constexpr int NIT = (TC * NRT + 511) / 512;
+  constexpr int NIT = (TC * NRT + TILE_THREADS - 1) / TILE_THREADS;
   double xv[NIT];
   int64_t xi[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it)
   {
-    const int e = it * 512 + threadIdx.x;
+    const int e = it * TILE_THREADS + threadIdx.x;
     const int cl = e / NRT, i = e - cl * NRT;
     const int32_t cell = (e < TC * NRT) ? cells[cl] : -1;
     xi[it] = (cell >= 0) ? (int64_t)cell * NRT + i : -1;
@@ -1413,7 +1417,7 @@ __global__ void __launch_bounds__(512, (K <= 2 ? 4 : 1)) k_se_patch_tiled(const 
 #pragma unroll
   for (int it = 0; it < NIT; ++it)
   {
-    const int e = it * 512 + threadIdx.x;
+    const int e = it * TILE_THREADS + threadIdx.x;
     const int cl = e / NRT, i = e - cl * NRT;
     if (xi[it] >= 0)
     {
@@ -1440,7 +1444,7 @@ static int launch_tiled_kd(const SeArgs& a, const TileArgs& t, hipStream_t strea
   }
   if (t.ntiles == 0)
     return 0;
-  hipLaunchKernelGGL(kern, dim3((unsigned)t.ntiles), dim3(512), lds_bytes, stream, a, t);
+  hipLaunchKernelGGL(kern, dim3((unsigned)t.ntiles), dim3(TILE_THREADS), lds_bytes, stream, a, t);
   return (hipGetLastError() == hipSuccess) ? 0 : EQLB_ERR_DEVICE;
 }
 
