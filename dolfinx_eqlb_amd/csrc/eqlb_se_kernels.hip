@@ -1060,33 +1060,49 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         ym[j] = s;
         yp[j] = mu_p[j] + ((j == 0) ? ul[0] : ul[KB + j]);
       }
-      double cout[NRT];
-#pragma unroll
-      for (int e = 0; e < 3 * K; ++e)
-      {
-        const int fe = e / K, j = e % K;
-        cout[e] = (fe == fm) ? pf_m * ym[j] : ((fe == fp) ? pf_p * yp[j] : 0.0);
-      }
-#pragma unroll
-      for (int q = 0; q < NDIV; ++q)
-        cout[3 * K + q] = Rq[1 + q];
-#pragma unroll
-      for (int q = 0; q < NADD; ++q)
-        cout[3 * K + NDIV + q] = sgn * ul[1 + 2 * KB + q]; // interior unknowns are scaled by sign(detJ),
-                                                          // so that the tensors TE/WQ carry no sign
-
       if constexpr (SCATTER == 2)
       {
-        // tiled launch: the row goes to the LDS slot of the owned cell; halo lanes drop it
+        // tiled launch: the row goes to the LDS slot of the owned cell (halo lanes drop it); the two
+        // patch facets are written at their offsets, the DOFs of the outer facet stay zero (the
+        // slots are zero-initialised and every row is written once) - no select chain
         const uint32_t loc = info >> INFO_LOCAL_SHIFT;
         if (loc != 0u)
         {
           double* o = tile_slots + ((int64_t)(loc - 1) * 3 + ln) * NRT;
 #pragma unroll
-          for (int e = 0; e < NRT; ++e)
-            o[e] = cout[e];
+          for (int j = 0; j < K; ++j)
+          {
+            o[fm * K + j] = pf_m * ym[j];
+            o[fp * K + j] = pf_p * yp[j];
+          }
+#pragma unroll
+          for (int q = 0; q < NDIV; ++q)
+            o[3 * K + q] = Rq[1 + q];
+#pragma unroll
+          for (int q = 0; q < NADD; ++q)
+            o[3 * K + NDIV + q] = sgn * ul[1 + 2 * KB + q];
         }
-        (void)0;
+      }
+      double cout[(SCATTER == 2) ? 1 : NRT];
+      if constexpr (SCATTER != 2)
+      {
+#pragma unroll
+        for (int e = 0; e < 3 * K; ++e)
+        {
+          const int fe = e / K, j = e % K;
+          cout[e] = (fe == fm) ? pf_m * ym[j] : ((fe == fp) ? pf_p * yp[j] : 0.0);
+        }
+#pragma unroll
+        for (int q = 0; q < NDIV; ++q)
+          cout[3 * K + q] = Rq[1 + q];
+#pragma unroll
+        for (int q = 0; q < NADD; ++q)
+          cout[3 * K + NDIV + q] = sgn * ul[1 + 2 * KB + q]; // interior unknowns are scaled by sign(detJ),
+                                                            // so that the tensors TE/WQ carry no sign
+      }
+      (void)cout;
+      if constexpr (SCATTER == 2)
+      {
       }
       else if constexpr (SCATTER == 0)
       {
