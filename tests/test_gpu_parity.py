@@ -246,3 +246,20 @@ def test_lower_degree_data_is_embedded(cpp, oracle_mod, k, deg):
     with pytest.raises(RuntimeError, match="Wrong polynomial degree"):
         Gh, fh = make_compatible_data(mesh, 2, ft)
         FluxEqlbSE(1, mesh, [fh], [Gh])
+
+
+@pytest.mark.parametrize("scale,shift", [(1e-6, 0.0), (1e5, 0.0), (1e-3, 250.0)])
+def test_geometry_scaling_and_offset(cpp, oracle_mod, scale, shift):
+    """Tiny / huge / far-from-origin cells: the Newton-refined reciprocals of the kernels and the
+    centroid-based tiling must not depend on the length scale."""
+    from dolfinx_eqlb_amd.mesh import create_mesh, create_unit_square
+    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    k = 2
+    base = create_unit_square(9, shuffle_seed=21, perturb=0.3)
+    mesh = create_mesh(base.x[:, :2] * scale + shift, base.cell_nodes)
+    ft = facet_types(mesh, None)
+    G, f = make_compatible_data(mesh, k, ft)
+    ref = oracle_mod.se_reconstruct(mesh, k, ft, G[None], f[None])
+    for scatter in (0, 2):
+        x, _ = _gpu(cpp, mesh, k, ft, G[None], f[None], scatter=scatter)
+        assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max()
