@@ -436,6 +436,10 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
       return fail(EQLB_ERR_UNSUPPORTED,
                   "inhomogeneous flux BCs with stress equilibration are not in this build");
   }
+  h->stress_flux_bcs = false;
+  if (h->stress)
+    for (size_t i = 0; i < (size_t)2 * m.nfacets && !h->stress_flux_bcs; ++i)
+      h->stress_flux_bcs = (facet_type[i] == EQLB_FACET_ESSNT_DUAL);
   // OrientedPatch::set_max_patch_size (se/Patch.cpp:337-404): every local node is checked
   for (int32_t i = 0; i < m.nnodes; ++i)
   {
@@ -838,7 +842,7 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
       a.npatch = h->bins[b].npatch;
       a.slot_offset = h->bins[b].slot_offset;
       a.patch_offset = h->bins[b].patch_offset;
-      const int st = eqlb::launch_se_weaksym(h->k, h->bins[b].P, a, stream);
+      const int st = eqlb::launch_se_weaksym(h->k, h->bins[b].P, !h->stress_flux_bcs, a, stream);
       if (st)
         return fail(st, "weak-symmetry kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
     }

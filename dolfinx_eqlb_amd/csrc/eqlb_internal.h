@@ -141,7 +141,7 @@ int launch_se_patch_tiled(int k, int deg, int mode, const SeArgs& a, const TileA
 void launch_tile_facet_owner(const DeviceMesh& m, int64_t n, const int32_t* tile_cells, int32_t* code,
                              hipStream_t stream);
 int tile_cells_of(int k);
-int launch_se_weaksym(int k, int P, const SeArgs& a, hipStream_t stream);
+int launch_se_weaksym(int k, int P, bool no_flux_bcs, const SeArgs& a, hipStream_t stream);
 int launch_ev_patch_fused(int k, const SeArgs& a, const FusedBins& fb, hipStream_t stream);
 // conforming <-> broken layout of the EV equilibrator (eqlb_ev.hip); cell_dofs may be nullptr
 // (default numbering: facet*k + j, then nfacets*k + cell*(k^2-k) + i)
@@ -191,6 +191,7 @@ struct eqlb_se
   int ev_output = 0;                // EV: 0 conforming DOFs, 1 broken hierarchic RT_k layout
   int32_t* ev_cell_dofs = nullptr;  // EV: device copy of the caller's dofmap or nullptr (default)
   int64_t ev_ndofs = 0;             // EV: number of conforming flux DOFs
+  bool stress_flux_bcs = true;       // some facet of stress row 0 / 1 carries a flux BC
   bool boundary_set = false;
   int64_t npatch_total = 0, nslots = 0;
   eqlb::Bin bins[eqlb::MAX_BINS];

@@ -281,6 +281,12 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
   constexpr int NLR = W::REG_A ? W::TRI : 1, NDR = W::REG_A ? W::DIMMAX : 1;
   double Lr[NLR], Dr[NDR];
   const bool use_reg = W::REG_A && !requires_bcs; // uniform within a patch group
+#ifdef EQLB_WS_SKIP_CHOL // timing experiment (wrong results)
+  for (int i = 0; i < NLR; ++i)
+    Lr[i] = 1.0;
+  for (int i = 0; i < NDR; ++i)
+    Dr[i] = 1.0;
+#else
   if constexpr (W::REG_A)
   {
     if (use_reg)
@@ -339,6 +345,8 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
         wave_sync();
       }
     }
+#ifndef EQLB_WS_SKIP_Y
+#endif
   // ---- Y_k = L_k^-1 B_k: every lane forward-substitutes whole columns ----
   for (int col = sub; col < 2 * npnt; col += P)
   {
@@ -403,6 +411,8 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
     }
   }
   wave_sync();
+#ifndef EQLB_WS_SKIP_SCHUR
+#endif
   // ---- Schur complement C -= sum_k Y_k^T Y_k ----
   for (int e = sub; e < npnt * npnt; e += P)
   {
@@ -414,6 +424,8 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
     Cg[r * DCMAX + c] -= t;
   }
   wave_sync();
+#endif
+#ifndef EQLB_WS_SKIP_LU
   // ---- dense LU with partial pivoting of the (npnt [+1])^2 Schur system ----
   if constexpr (W::REG_LU)
   {
@@ -558,6 +570,7 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
     }
   }
   wave_sync();
+#endif
   // ---- u_k = -L_k^-T (Y_k gamma) ----
   for (int e = sub; e < 2 * dim; e += P)
   {
@@ -644,6 +657,456 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
     atomicOr(a.status, 2);
 }
 
+// ---- lean variant: k = 2, patches of up to 8 cells, NO flux BCs on the stress rows -----------------
+// (the benchmark / pure-Dirichlet case).  Same mathematics, a fraction of the LDS: the Cholesky
+// factor of A (<= 9 x 9) is computed in registers and parked in LDS, the Schur system lives in
+// registers from the start (rows r = sub, sub + P, the layout of the distributed LU), Y_k = L^-1 B_k
+// is formed per stress row in one 9 x 10 buffer and re-formed after the LU instead of being kept.
+// 184 doubles of LDS per patch instead of 438 -> about three times the resident waves.
+template <int P>
+struct WsLean
+{
+  static constexpr int K = 2;
+  using Z = Sizes<K, K - 1, P>;
+  static constexpr int NH = Z::NH, NRT = Z::NRT, NTE = Z::NTE;
+  static constexpr int DM = Z::DIMMAX;     // 1 + P  (<= 9)
+  static constexpr int TRI = DM * (DM + 1) / 2;
+  static constexpr int NPM = P + 2, DCM = NPM + 1, LDB = NPM;
+  // per patch: L (packed lower) | 1/L_ii | Yb [DM][LDB] | Mv [NPM] | R [DCM] | W [2][DM]
+  static constexpr int OFF_D = TRI, OFF_Y = OFF_D + DM, OFF_M = OFF_Y + DM * LDB, OFF_R = OFF_M + NPM,
+                       OFF_W = OFF_R + DCM, GROUP = OFF_W + 2 * DM;
+  static constexpr int NTAB = Z::NTET + Z::NVT + Z::NVQT;
+  static constexpr int BLOCK = 256;
+  static constexpr int lds_doubles() { return NTAB + (BLOCK / P) * GROUP; }
+};
+
+template <int P>
+__global__ void __launch_bounds__(256, 2) k_se_weaksym_lean(const SeArgs a)
+{
+  using W = WsLean<P>;
+  using Z = typename W::Z;
+  constexpr int K = 2, KB = 1, NH = W::NH, NRT = W::NRT, NTE = W::NTE, DM = W::DM, DCM = W::DCM, LDB = W::LDB;
+  static_assert(DM <= 9 && NH == 3, "lean weak-symmetry kernel: k = 2, at most 8 cells");
+
+  extern __shared__ double lds[];
+  double* sTE = lds;
+  double* sV = sTE + Z::NTET;
+  double* sVQ = sV + Z::NVT;
+  double* sG = sVQ + Z::NVQT;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < Z::NTET; i += W::BLOCK)
+    sTE[i] = a.tables[Z::OFF_TE + i];
+  for (int i = tid; i < Z::NVT + Z::NVQT; i += W::BLOCK)
+    sV[i] = a.tables[Z::OFF_V + i];
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int sub = lane % P;
+  const int gb = lane - sub;
+  const int64_t patch_local = ((int64_t)blockIdx.x * W::BLOCK + tid) / P;
+  const bool pvalid = patch_local < a.npatch;
+  const int64_t slot = a.slot_offset + patch_local * P + sub;
+  const int64_t patch = a.patch_offset + patch_local;
+  const int n = pvalid ? (int)a.pn[patch] : 0;
+  const bool active = pvalid && sub < n;
+  const int32_t cell = active ? a.slot_cell[slot] : 0;
+  const uint32_t info = active ? a.slot_info[slot] : 0u;
+  const int fm = (info >> INFO_FM_SHIFT) & 3, fp = (info >> INFO_FP_SHIFT) & 3;
+  const int ln = (info >> INFO_LN_SHIFT) & 3;
+  const bool rev_m = (info & INFO_REV_M) != 0;
+  const int ci = (fm * 3 + fp) * 2 + (rev_m ? 1 : 0);
+
+  double J[2][2] = {{1.0, 0.0}, {0.0, 1.0}};
+  if (active)
+  {
+    const double2* Jp = reinterpret_cast<const double2*>(a.cellJ + 4 * (int64_t)cell);
+    const double2 j0 = Jp[0], j1 = Jp[1];
+    J[0][0] = j0.x;
+    J[0][1] = j0.y;
+    J[1][0] = j1.x;
+    J[1][1] = j1.y;
+  }
+  const double detJ = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+  const double sgn = (detJ > 0.0) ? 1.0 : -1.0;
+  const double pf_m = (fm == 1) ? sgn : -sgn, pf_p = (fp == 1) ? sgn : -sgn;
+
+  const uint8_t flag0 = pvalid ? a.pflag[patch] : (uint8_t)PFLAG_INTERIOR;
+  const bool interior = (flag0 & PFLAG_INTERIOR) != 0;
+  const int nf = interior ? n : n + 1;
+  const int nn = (n > 0) ? n : 1;
+  const int fi_p = interior ? ((sub + 1 < nn) ? sub + 1 : 0) : sub + 1;
+  const int dim = pvalid ? 1 + nf : 0;
+  const int npnt = nf + 1;
+  const bool meanvalue = interior; // no flux BCs: boundary patches are of type essnt_primal
+  const int dim_c = pvalid ? (meanvalue ? npnt + 1 : npnt) : 0;
+
+  double* Lg = sG + (tid / P) * W::GROUP;
+  double* Dg = Lg + W::OFF_D;
+  double* Yb = Lg + W::OFF_Y;
+  double* Mv = Lg + W::OFF_M;
+  double* Rg = Lg + W::OFF_R;
+  double* Wg = Lg + W::OFF_W;
+
+  // numbering (as in k_se_weaksym)
+  int gi[NH];
+  gi[0] = 0;
+  gi[1] = 1 + sub;
+  gi[2] = 1 + fi_p;
+  int pj[3];
+  {
+    const int v_ea = 3 - fp - ln, v_eam1 = 3 - fm - ln;
+    const int p_ea = interior ? sub + 1 : ((sub + 1 == n) ? nf : sub + 1);
+    const int p_eam1 = interior ? ((sub == 0) ? n : sub) : ((sub == 0) ? nf - 1 : sub);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      pj[j] = (j == ln) ? 0 : ((j == v_ea) ? p_ea : ((j == v_eam1) ? p_eam1 : 0));
+  }
+
+  // ---- zero the tile, assemble A, the mean-value coupling and the right-hand side ----
+  for (int e = sub; e < W::GROUP; e += P)
+    Lg[e] = 0.0;
+  wave_sync();
+  double* srow[2] = {nullptr, nullptr};
+  if (active)
+  {
+    const double ia = 1.0 / fabs(detJ);
+    const double g0 = (J[0][0] * J[0][0] + J[1][0] * J[1][0]) * ia,
+                 g1 = (J[0][0] * J[0][1] + J[1][0] * J[1][1]) * ia,
+                 g2 = (J[0][1] * J[0][1] + J[1][1] * J[1][1]) * ia;
+    const double* te = sTE + ci * 3 * NTE;
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int g = 0; g < NH; ++g)
+      {
+        const int hh = (h > g) ? h : g, gg = (h > g) ? g : h;
+        const int e = hh * (hh + 1) / 2 + gg;
+        if (gi[h] >= gi[g])
+          atomicAdd(&Lg[tri(gi[h], gi[g])], g0 * te[e] + g1 * te[NTE + e] + g2 * te[2 * NTE + e]);
+      }
+    srow[0] = a.out + (((int64_t)0 * a.ncells + cell) * 3 + ln) * NRT;
+    srow[1] = a.out + (((int64_t)1 * a.ncells + cell) * 3 + ln) * NRT;
+    double Lce[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < NRT; ++i)
+    {
+      const double c0 = srow[0][i], c1 = srow[1][i];
+      const double w0 = c0 * J[1][0] - c1 * J[0][0], w1 = c0 * J[1][1] - c1 * J[0][1];
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        Lce[j] -= sgn * (w0 * sV[(j * NRT + i) * 2] + w1 * sV[(j * NRT + i) * 2 + 1]);
+    }
+    const double Ce = fabs(detJ) / 6.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+    {
+      atomicAdd(&Rg[pj[j]], Lce[j]);
+      atomicAdd(&Mv[pj[j]], Ce);
+    }
+  }
+  wave_sync();
+
+  // ---- Cholesky of A in registers (every lane of the group the same), parked in LDS ----
+  int status_local = 0;
+  {
+    double Lr[W::TRI];
+#pragma unroll
+    for (int i = 0; i < DM; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j)
+        Lr[tri(i, j)] = (i < dim) ? Lg[tri(i, j)] : ((i == j) ? 1.0 : 0.0);
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < DM; ++j)
+    {
+      const double ajj = Lr[tri(j, j)];
+      if (!(ajj > 0.0))
+        status_local = pvalid ? 1 : status_local;
+      const double inv = rsqrt_d(ajj > 0.0 ? ajj : 1.0);
+      Lr[tri(j, j)] = (ajj > 0.0 ? ajj : 1.0) * inv;
+      if (sub == 0)
+        Dg[j] = inv;
+#pragma unroll
+      for (int i = j + 1; i < DM; ++i)
+        Lr[tri(i, j)] *= inv;
+#pragma unroll
+      for (int i = j + 1; i < DM; ++i)
+#pragma unroll
+        for (int kk = j + 1; kk <= i; ++kk)
+          Lr[tri(i, kk)] -= Lr[tri(i, j)] * Lr[tri(kk, j)];
+    }
+    // each lane writes a share of the factor back
+#pragma unroll
+    for (int e = 0; e < W::TRI; ++e)
+      if ((e % P) == sub)
+        Lg[e] = Lr[e];
+  }
+  wave_sync();
+
+  // B_k of this lane's cell: Be[h][j], k = 0: int (Phi_h)_y psi_j, k = 1: -int (Phi_h)_x psi_j
+  auto form_Y = [&](int k, double (&y0)[DM], double (&y1)[DM]) {
+    // assemble B_k into Yb, then columns c = sub and sub + P: y = L^-1 b
+    for (int e = sub; e < DM * LDB; e += P)
+      Yb[e] = 0.0;
+    wave_sync();
+    if (active)
+    {
+      const double* vq = sVQ + ci * 2 * NH * 3;
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+        {
+          const double v0 = vq[h * 3 + j], v1 = vq[(NH + h) * 3 + j];
+          const double b = (k == 0) ? (J[1][0] * v0 + J[1][1] * v1) : -(J[0][0] * v0 + J[0][1] * v1);
+          atomicAdd(&Yb[gi[h] * LDB + pj[j]], b);
+        }
+    }
+    wave_sync();
+    const bool h0 = sub < npnt, h1 = sub + P < npnt;
+#pragma unroll
+    for (int i = 0; i < DM; ++i)
+    {
+      y0[i] = (h0 && i < dim) ? Yb[i * LDB + sub] : 0.0;
+      y1[i] = (h1 && i < dim) ? Yb[i * LDB + sub + P] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < DM; ++i)
+    {
+      double t0 = y0[i], t1 = y1[i];
+#pragma unroll
+      for (int q = 0; q < i; ++q)
+      {
+        const double l = Lg[tri(i, q)];
+        t0 -= l * y0[q];
+        t1 -= l * y1[q];
+      }
+      const double d = Dg[i];
+      y0[i] = (i < dim) ? t0 * d : 0.0;
+      y1[i] = (i < dim) ? t1 * d : 0.0;
+    }
+  };
+
+  // ---- Schur system [C | rhs] in registers: rows r = sub and r = sub + P ----
+  double r0[DCM + 1], r1[DCM + 1];
+#pragma unroll
+  for (int j = 0; j <= DCM; ++j)
+    r0[j] = r1[j] = 0.0;
+  if (pvalid)
+  {
+    if (meanvalue)
+    {
+      // multiplier row / column: int psi_j over the patch
+#pragma unroll
+      for (int j = 0; j < DCM; ++j)
+      {
+        if (j == npnt)
+        {
+          r0[j] = (sub < npnt) ? Mv[sub] : 0.0;
+          r1[j] = (sub + P < npnt) ? Mv[sub + P] : 0.0;
+        }
+        if (j < npnt)
+        {
+          if (sub == npnt)
+            r0[j] = Mv[j];
+          if (sub + P == npnt)
+            r1[j] = Mv[j];
+        }
+      }
+    }
+    r0[DCM] = (sub < npnt) ? Rg[sub] : 0.0;
+    r1[DCM] = (sub + P < npnt) ? Rg[sub + P] : 0.0;
+  }
+  for (int k = 0; k < 2; ++k)
+  {
+    double y0[DM], y1[DM];
+    form_Y(k, y0, y1);
+    // publish the substituted columns, then C[r][c] -= y_r . y_c for the lane's rows
+#pragma unroll
+    for (int i = 0; i < DM; ++i)
+    {
+      if (sub < npnt && i < dim)
+        Yb[i * LDB + sub] = y0[i];
+      if (sub + P < npnt && i < dim)
+        Yb[i * LDB + sub + P] = y1[i];
+    }
+    wave_sync();
+#pragma unroll
+    for (int c = 0; c < W::NPM; ++c)
+    {
+      if (c < npnt)
+      {
+        double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < DM; ++i)
+        {
+          const double yc = (i < dim) ? Yb[i * LDB + c] : 0.0;
+          t0 += y0[i] * yc;
+          t1 += y1[i] * yc;
+        }
+        r0[c] -= t0;
+        r1[c] -= t1;
+      }
+    }
+    wave_sync();
+  }
+
+  // ---- distributed LU with partial pivoting (as in k_se_weaksym) ----
+  double gam[DCM];
+  {
+    bool free0 = sub < dim_c, free1 = sub + P < dim_c;
+    int prow[DCM];
+#pragma unroll
+    for (int c = 0; c < DCM; ++c)
+    {
+      prow[c] = 0;
+      if (c < dim_c)
+      {
+        double bv = free0 ? fabs(r0[c]) : -1.0;
+        int br = sub;
+        const double v1 = free1 ? fabs(r1[c]) : -1.0;
+        if (v1 > bv)
+        {
+          bv = v1;
+          br = sub + P;
+        }
+#pragma unroll
+        for (int off = 1; off < P; off <<= 1)
+        {
+          const double ov = __shfl(bv, gb + (sub ^ off), 64);
+          const int orow = __shfl(br, gb + (sub ^ off), 64);
+          if (ov > bv || (ov == bv && orow < br))
+          {
+            bv = ov;
+            br = orow;
+          }
+        }
+        if (!(bv > 0.0))
+          status_local = pvalid ? 1 : status_local;
+        prow[c] = br;
+        const int owner = gb + (br % P);
+        const bool second = br >= P;
+        double pr[DCM + 1];
+#pragma unroll
+        for (int j = c; j <= DCM; ++j)
+          pr[j] = __shfl(second ? r1[j] : r0[j], owner, 64);
+        const double ip = rcp_d((pr[c] != 0.0) ? pr[c] : 1.0);
+        if (br == sub)
+          free0 = false;
+        if (br == sub + P)
+          free1 = false;
+        const double f0 = free0 ? r0[c] * ip : 0.0, f1 = free1 ? r1[c] * ip : 0.0;
+#pragma unroll
+        for (int j = c; j <= DCM; ++j)
+        {
+          r0[j] -= f0 * pr[j];
+          r1[j] -= f1 * pr[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = DCM - 1; c >= 0; --c)
+    {
+      gam[c] = 0.0;
+      if (c < dim_c)
+      {
+        const int br = prow[c];
+        const bool second = br >= P;
+        double t = second ? r1[DCM] : r0[DCM];
+#pragma unroll
+        for (int j = c + 1; j < DCM; ++j)
+          t -= (second ? r1[j] : r0[j]) * gam[j];
+        const double d = second ? r1[c] : r0[c];
+        t *= rcp_d((d != 0.0) ? d : 1.0);
+        gam[c] = __shfl(t, gb + (br % P), 64);
+      }
+    }
+  }
+
+  // ---- u_k = -L^-T (Y_k gamma): partial sums over the lane's columns, group sum, back substitution ----
+  for (int k = 0; k < 2; ++k)
+  {
+    double y0[DM], y1[DM];
+    form_Y(k, y0, y1);
+    double g0 = 0.0, g1 = 0.0; // gamma of the lane's columns
+#pragma unroll
+    for (int c = 0; c < W::NPM; ++c)
+    {
+      if (c == sub)
+        g0 = gam[c];
+      if (c == sub + P)
+        g1 = gam[c];
+    }
+    double w[DM];
+#pragma unroll
+    for (int i = 0; i < DM; ++i)
+      w[i] = -group_sum_d<P>(y0[i] * g0 + y1[i] * g1, gb, sub);
+#pragma unroll
+    for (int i = DM - 1; i >= 0; --i)
+    {
+      double t = w[i];
+#pragma unroll
+      for (int q = i + 1; q < DM; ++q)
+        t -= Lg[tri(q, i)] * w[q];
+      w[i] = (i < dim) ? t * Dg[i] : 0.0;
+    }
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < DM; ++i)
+      if (sub == 0 && pvalid)
+        Wg[k * DM + i] = w[i];
+    wave_sync();
+  }
+
+  // ---- back-map and add to the slot rows (se/solve_patch_weaksym.hpp:189-232) ----
+  if (active)
+  {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+    {
+      const double* w = Wg + k * DM;
+      double ul[NH];
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+        ul[h] = w[gi[h]];
+      double* o = srow[k];
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+      {
+        double sacc = 0.0;
+#pragma unroll
+        for (int c = 0; c < K; ++c)
+          sacc -= (rev_m ? bcoef(j, c) : ((j == c) ? 1.0 : 0.0)) * ul[c];
+        const double yp = (j == 0) ? ul[0] : ul[KB + j];
+        o[fm * K + j] += pf_m * sacc;
+        o[fp * K + j] += pf_p * yp;
+      }
+    }
+  }
+  if (status_local)
+    atomicOr(a.status, 2);
+}
+
+template <int P>
+static int launch_ws_lean(const SeArgs& a, hipStream_t stream)
+{
+  using W = WsLean<P>;
+  const size_t lds_bytes = sizeof(double) * (size_t)W::lds_doubles();
+  auto kern = k_se_weaksym_lean<P>;
+  if (lds_bytes > 64 * 1024)
+  {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
+        != hipSuccess)
+      return EQLB_ERR_DEVICE;
+  }
+  const int64_t grid = (a.npatch * P + W::BLOCK - 1) / W::BLOCK;
+  if (grid == 0)
+    return 0;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(W::BLOCK), lds_bytes, stream, a);
+  return (hipGetLastError() == hipSuccess) ? 0 : EQLB_ERR_DEVICE;
+}
+
 template <int K, int P>
 static int launch_ws_t(const SeArgs& a, hipStream_t stream)
 {
@@ -685,8 +1148,12 @@ static int launch_ws_k(int P, const SeArgs& a, hipStream_t stream)
   return EQLB_ERR_UNSUPPORTED;
 }
 
-int launch_se_weaksym(int k, int P, const SeArgs& a, hipStream_t stream)
+int launch_se_weaksym(int k, int P, bool no_flux_bcs, const SeArgs& a, hipStream_t stream)
 {
+  if (k == 2 && no_flux_bcs && P == 4)
+    return launch_ws_lean<4>(a, stream);
+  if (k == 2 && no_flux_bcs && P == 8)
+    return launch_ws_lean<8>(a, stream);
   if (k == 2)
     return launch_ws_k<2>(P, a, stream);
   if (k == 3)
