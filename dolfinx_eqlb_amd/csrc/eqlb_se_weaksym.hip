@@ -663,6 +663,9 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
 // registers from the start (rows r = sub, sub + P, the layout of the distributed LU), Y_k = L^-1 B_k
 // is formed per stress row in one 9 x 10 buffer and re-formed after the LU instead of being kept.
 // 184 doubles of LDS per patch instead of 438 -> about three times the resident waves.
+#ifndef EQLB_WS_LEAN_WAVES
+#define EQLB_WS_LEAN_WAVES 2
+#endif
 template <int P>
 struct WsLean
 {
@@ -681,7 +684,7 @@ struct WsLean
 };
 
 template <int P>
-__global__ void __launch_bounds__(256, 2) k_se_weaksym_lean(const SeArgs a)
+__global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(const SeArgs a)
 {
   using W = WsLean<P>;
   using Z = typename W::Z;
