@@ -127,15 +127,6 @@ __device__ __forceinline__ double rsqrt_d(double x)
 }
 
 
-// A/B switches of the memory path: cooperative LDS staging of the input
-// rows (LDS-DMA) and of the output slot rows; off by default (measured slower)
-#ifndef EQLB_STAGE_IN
-#define EQLB_STAGE_IN 0
-#endif
-#ifndef EQLB_STAGE_OUT
-#define EQLB_STAGE_OUT 0
-#endif
-
 // ---- compile-time sizes of a (K, DEG, P) patch kernel ------------------------------------------
 template <int K, int DEG, int P>
 struct Sizes
@@ -162,16 +153,9 @@ struct Sizes
   static constexpr int NHG = ND * NQ, NWG = 18 * NH * ND * 2, NEV = NHG + NWG;
   static constexpr int OFF_HG = OFF_VQ + NVQT;
   // workgroup size: as many waves as fit a 64 KiB LDS budget for the dense tiles (at least one)
-  // per-wave staging of the gathered input rows (G, f, J of 64 cells) / the output rows
-  static constexpr int FB = ((8 * ND) % 16 == 0) ? 16 : 4; // f-row piece (LDS-DMA: 16 or 4 bytes)
-  static constexpr int NCF = 8 * ND / FB;
-  static constexpr int STG_G = 64 * ND * 2, STG_F = 64 * ND, STG_J = 64 * 4;
-  static constexpr int STG_IN = STG_G + STG_F + STG_J, STG_OUT = 64 * NRT;
-  static constexpr int STG = (EQLB_STAGE_IN || EQLB_STAGE_OUT) ? ((STG_IN > STG_OUT) ? STG_IN : STG_OUT) : 0;
   static constexpr int lds_doubles(int block, int solver, int mode = 0)
   {
-    return NTAB + (mode ? NEV : 0) + (block / 64) * STG
-           + ((K > 1 && solver == 0) ? (block / P) * LDS_GROUP : 0);
+    return NTAB + (mode ? NEV : 0) + ((K > 1 && solver == 0) ? (block / P) * LDS_GROUP : 0);
   }
   static constexpr int block_of(int solver)
   {

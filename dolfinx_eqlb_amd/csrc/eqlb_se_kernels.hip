@@ -72,15 +72,6 @@ int fill_tables_host(int k, int deg, std::vector<double>& out)
   return (out.size() == table_doubles(k, deg)) ? 0 : EQLB_ERR_UNSUPPORTED;
 }
 
-// A/B switches of the memory path: cooperative LDS staging of the input
-// rows (LDS-DMA) and of the output slot rows
-#ifndef EQLB_STAGE_IN
-#define EQLB_STAGE_IN 0
-#endif
-#ifndef EQLB_STAGE_OUT
-#define EQLB_STAGE_OUT 0
-#endif
-
 // ---- the patch kernel ---------------------------------------------------------------------------
 // MODE 0: semi-explicit equilibration.  MODE 1: the constrained-minimisation patch problem of
 // ev/solve_patch.hpp:58-238 (mixed RT_k x DG_{k-1} saddle point, (ndof+1)^2 LU per patch in the
@@ -105,9 +96,8 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   double* sHB = sWQ + Z::NWQT;                    // [3][3][K][K]
   double* sHG = sHB + Z::NHB;                     // MODE 1: [ND][NQ]
   double* sWG = sHG + Z::NHG;                     // MODE 1: [18][NH][ND][2]
-  double* sStage = sHB + Z::NHB + (MODE ? Z::NEV : 0); // per-wave row staging
   (void)sWG;
-  double* sA = sStage + (BLOCK / 64) * Z::STG;    // SOLVER 0: per-group tiles
+  double* sA = sHB + Z::NHB + (MODE ? Z::NEV : 0); // SOLVER 0: per-group tiles
   (void)sA;
 
   const int tid = threadIdx.x;
@@ -143,62 +133,13 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   const bool rev_m = (info & INFO_REV_M) != 0, rev_p = (info & INFO_REV_P) != 0;
   const int ci = (fm * 3 + fp) * 2 + (rev_m ? 1 : 0); // row of the reduced tensors
 
-  // ---- cooperative gather of this wave's input rows into LDS (LDS-DMA) ----
-  // A per-lane row load touches 64 different cache lines per wave instruction; here consecutive
-  // lanes fetch consecutive 16-byte chunks of a row, so an instruction covers 64/CH whole rows.
   const int r = a.rhs; // one right-hand side per launch
-  double* stg = sStage + (tid >> 6) * Z::STG;
-  double* stgG = stg;
-  double* stgF = stg + Z::STG_G;
-  double* stgJ = stgF + Z::STG_F;
-  if constexpr (EQLB_STAGE_IN)
-  {
-    using gptr = const __attribute__((address_space(1))) void*;
-    using lptr = __attribute__((address_space(3))) void*;
-    const int wl0 = lane & ~63; // == 0: lane ids within the wave are 0..63
-    (void)wl0;
-    // G rows: ND chunks of 16 B (one DG node each)
-#pragma unroll
-    for (int i = 0; i < ND; ++i)
-    {
-      const int idx = i * 64 + lane, rr = idx / ND, cc = idx - rr * ND;
-      const int32_t cell_r = __shfl(cell, rr, 64);
-      const double* src = a.flux_dg + (((int64_t)r * a.ncells + cell_r) * ND + cc) * 2;
-      __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(stgG + i * 128), 16, 0, 0);
-    }
-    // f rows: 8 ND bytes in chunks of 16 / 12 / 4 bytes
-    constexpr int FB = Z::FB, NCF = Z::NCF;
-#pragma unroll
-    for (int i = 0; i < NCF; ++i)
-    {
-      const int idx = i * 64 + lane, rr = idx / NCF, cc = idx - rr * NCF;
-      const int32_t cell_r = __shfl(cell, rr, 64);
-      const char* src = reinterpret_cast<const char*>(a.rhs_dg + ((int64_t)r * a.ncells + cell_r) * ND) + cc * FB;
-      if constexpr (FB == 16)
-        __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(reinterpret_cast<char*>(stgF) + i * 64 * 16), 16, 0, 0);
-      else if constexpr (FB == 12)
-        __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(reinterpret_cast<char*>(stgF) + i * 64 * 12), 12, 0, 0);
-      else
-        __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(reinterpret_cast<char*>(stgF) + i * 64 * 4), 4, 0, 0);
-    }
-    // J rows: 2 chunks of 16 B
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-    {
-      const int idx = i * 64 + lane, rr = idx >> 1, cc = idx & 1;
-      const int32_t cell_r = __shfl(cell, rr, 64);
-      const double* src = a.cellJ + 4 * (int64_t)cell_r + 2 * cc;
-      __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(stgJ + i * 128), 16, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
 
   // ---- geometry (cached affine map) ----
   double J00 = 1.0, J01 = 0.0, J10 = 0.0, J11 = 1.0;
   if (active)
   {
-    const double2* Jp = EQLB_STAGE_IN ? reinterpret_cast<const double2*>(stgJ + 4 * lane)
-                                      : reinterpret_cast<const double2*>(a.cellJ + 4 * (int64_t)cell);
+    const double2* Jp = reinterpret_cast<const double2*>(a.cellJ + 4 * (int64_t)cell);
     const double2 j0 = Jp[0], j1 = Jp[1];
     J00 = j0.x;
     J01 = j0.y;
@@ -284,10 +225,8 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       }
       else if (active)
       {
-        const double2* gp_ = EQLB_STAGE_IN
-                                 ? reinterpret_cast<const double2*>(stgG + lane * (ND * 2))
-                                 : reinterpret_cast<const double2*>(a.flux_dg + ((int64_t)r * a.ncells + cell) * (ND * 2));
-        const double* fp_ = EQLB_STAGE_IN ? stgF + lane * ND : a.rhs_dg + ((int64_t)r * a.ncells + cell) * ND;
+        const double2* gp_ = reinterpret_cast<const double2*>(a.flux_dg + ((int64_t)r * a.ncells + cell) * (ND * 2));
+        const double* fp_ = a.rhs_dg + ((int64_t)r * a.ncells + cell) * ND;
         const double* tF_m = sF + (fm * 3 + ln) * ND * K;
         const double* tF_p = sF + (fp * 3 + ln) * ND * K;
         const double* tH = sH + ln * ND * NQ;
@@ -1106,11 +1045,11 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       }
       else if constexpr (SCATTER == 0)
       {
-        // stage the row; the wave stores all rows cooperatively below (or store it directly)
+        // every (cell, vertex) row of the slot buffer is written exactly once
 #ifdef EQLB_EXP_SLOTROW // timing experiment (wrong results): rows of consecutive lanes are contiguous
         double* o = a.out + (slot % ((int64_t)a.ncells * 3)) * NRT;
 #else
-        double* o = EQLB_STAGE_OUT ? stg + lane * NRT : a.out + (((int64_t)r * a.ncells + cell) * 3 + ln) * NRT;
+        double* o = a.out + (((int64_t)r * a.ncells + cell) * 3 + ln) * NRT;
 #endif
 #pragma unroll
         for (int e = 0; e < NRT; ++e)
@@ -1122,37 +1061,6 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 #pragma unroll
         for (int e = 0; e < NRT; ++e)
           unsafeAtomicAdd(o + e, cout[e]);
-      }
-    }
-    if constexpr (SCATTER == 0 && EQLB_STAGE_OUT)
-    {
-      // cooperative store of the 64 slot rows: consecutive lanes write consecutive pieces of a row
-      const int64_t key = active ? ((int64_t)r * a.ncells + cell) * 3 + ln : (int64_t)-1;
-      const int key_lo = (int)(key & 0xffffffff), key_hi = (int)(key >> 32);
-      if constexpr (NRT % 2 == 0)
-      {
-        constexpr int CH = NRT / 2; // 16-byte pieces per row
-#pragma unroll
-        for (int i = 0; i < CH; ++i)
-        {
-          const int idx = i * 64 + lane, rr = idx / CH, cc = idx - rr * CH;
-          const int64_t kr = ((int64_t)__shfl(key_hi, rr, 64) << 32) | (uint32_t)__shfl(key_lo, rr, 64);
-          const double2 v = reinterpret_cast<const double2*>(stg)[idx];
-          if (kr >= 0)
-            reinterpret_cast<double2*>(a.out + kr * NRT)[cc] = v;
-        }
-      }
-      else
-      {
-#pragma unroll
-        for (int i = 0; i < NRT; ++i)
-        {
-          const int idx = i * 64 + lane, rr = idx / NRT, cc = idx - rr * NRT;
-          const int64_t kr = ((int64_t)__shfl(key_hi, rr, 64) << 32) | (uint32_t)__shfl(key_lo, rr, 64);
-          const double v = stg[idx];
-          if (kr >= 0)
-            a.out[kr * NRT + cc] = v;
-        }
       }
     }
   }
