@@ -1194,6 +1194,9 @@ int launch_ev_patch_fused(int k, const SeArgs& a, const FusedBins& fb, hipStream
 // cell (patches on the tile rim are solved by each tile they touch), writes the (cell, vertex) rows
 // of its OWN cells into LDS - every row exactly once, no atomics - and finally adds
 // row(v0) + row(v1) + row(v2) in fixed order to flux_hdiv: bitwise reproducible like the slot path.
+#ifndef EQLB_XCD_REMAP
+#define EQLB_XCD_REMAP 1
+#endif
 #ifndef EQLB_TILE_THREADS
 #define EQLB_TILE_THREADS 512
 #endif
@@ -1234,6 +1237,18 @@ void launch_tile_facet_owner(const DeviceMesh& m, int64_t n, const int32_t* tile
 
 // MODE 0: semi-explicit flux, flux_hdiv in the broken layout.  MODE 1: EV patch problems; flush to
 // the conforming DOFs (ta.facet_owner != nullptr) or to the broken layout ("output" = 1).
+// bijective XCD swizzle (cdna_hip_programming.md T1): block b of n -> position of b in the order
+// "all blocks of XCD label 0, then of label 1, ..."
+__device__ __forceinline__ int xcd_remap(int b, int n)
+{
+#if EQLB_XCD_REMAP
+  const int q = n / 8, r = n % 8, x = b % 8;
+  return ((x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
+#else
+  return b;
+#endif
+}
+
 template <int K, int DEG, int MODE>
 __global__ void __launch_bounds__(TILE_THREADS, (K <= 2 ? 4 : 1)) k_se_patch_tiled(const SeArgs a0, const TileArgs ta)
 {
@@ -1241,6 +1256,10 @@ __global__ void __launch_bounds__(TILE_THREADS, (K <= 2 ? 4 : 1)) k_se_patch_til
   using Z = Sizes<K, DEG, 8>;
   constexpr int NRT = Z::NRT;
   constexpr int TC = tile_cells_c(K);
+  // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, tiles are numbered along the
+  // bisection tree (neighbours in space are neighbours in index); give every XCD one contiguous
+  // range of tiles so that the rim cells two tiles share are read through the same L2
+  const int tile = xcd_remap(blockIdx.x, ta.ntiles);
   constexpr int NTABM = Z::NTAB + (MODE ? Z::NEV : 0);
   double* sSlots = lds + NTABM;
   for (int i = threadIdx.x; i < Z::NTAB; i += TILE_THREADS)
@@ -1252,7 +1271,7 @@ __global__ void __launch_bounds__(TILE_THREADS, (K <= 2 ? 4 : 1)) k_se_patch_til
     sSlots[i] = 0.0;
   __syncthreads();
 
-  const TileDesc& td = ta.tiles[blockIdx.x];
+  const TileDesc& td = ta.tiles[tile];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int NW = TILE_THREADS / 64;
   int u = wave;
@@ -1276,14 +1295,14 @@ __global__ void __launch_bounds__(TILE_THREADS, (K <= 2 ? 4 : 1)) k_se_patch_til
 #undef EQLB_TILE_BIN
   __syncthreads();
 
-  const int32_t* cells = ta.tile_cells + (int64_t)blockIdx.x * TC;
+  const int32_t* cells = ta.tile_cells + (int64_t)tile * TC;
   if (MODE == 1 && ta.facet_owner != nullptr)
   {
     // conforming DOFs (ev/solve_patch.hpp:223-227): facet DOFs by the first cell of the facet,
     // mapped to the global facet frame (T_f = -I / B), interior DOFs by their cell
     constexpr int NI = K * K - K;
     double* x = a0.out + (int64_t)a0.rhs * ta.ndofs;
-    const int32_t* own = ta.facet_owner + (int64_t)blockIdx.x * TC * 3;
+    const int32_t* own = ta.facet_owner + (int64_t)tile * TC * 3;
     for (int e = threadIdx.x; e < TC * 3; e += TILE_THREADS)
     {
       const int32_t code = own[e];
