@@ -55,6 +55,8 @@ void dfree(T*& p)
 void free_boundary(eqlb_se* h)
 {
   dfree(h->facet_type);
+  dfree(h->node_ws);
+  dfree(h->node_group);
   dfree(h->bvals);
   dfree(h->node_slot);
   dfree(h->node_patch);
@@ -73,6 +75,80 @@ void free_boundary(eqlb_se* h)
   h->ntiles = 0;
   h->boundary_set = false;
 }
+// Grouped boundary patches of the stress path (se/reconstruction.hpp:170-234, se/Patch.cpp:60-104,
+// 762-784; RT_2 only): a node whose two boundary facets carry flux BCs on both stress rows
+// (base/BoundaryData.cpp:611-631) and that has two cells is grouped with the adjacent internal patch.
+// The reference treats the groups one after the other in node order and lets a group see what the
+// earlier ones added to the global stress; on the device all row-wise sweeps come first, which is the
+// same thing as long as no cell of a group's internal patch has a vertex in another group - checked
+// here, overlapping groups are refused.  ws: 0 normal, 1 two-cell member, 2 internal patch.
+int find_stress_groups(const eqlb::DeviceMesh& m, const int8_t* facet_type, const uint8_t* node_mask,
+                       std::vector<int8_t>& ws, std::vector<int32_t>& group, bool& any)
+{
+  const int32_t nn = m.nnodes;
+  ws.assign(nn, 0);
+  group.assign(nn, -1);
+  any = false;
+  std::vector<int8_t> cnt(nn, 0);
+  for (int r = 0; r < 2; ++r)
+    for (int32_t f = 0; f < m.nfacets; ++f)
+      if (facet_type[(size_t)r * m.nfacets + f] == EQLB_FACET_ESSNT_DUAL)
+      {
+        ++cnt[m.h_facet_nodes[2 * (size_t)f]];
+        ++cnt[m.h_facet_nodes[2 * (size_t)f + 1]];
+      }
+  int32_t ngroups = 0;
+  for (int32_t node = 0; node < nn; ++node)
+  {
+    if (node_mask && !node_mask[node])
+      continue;
+    if (cnt[node] != 4 || group[node] >= 0 || m.h_node_ncells[node] != 2)
+      continue;
+    int32_t inner = -1;
+    for (int32_t q = m.h_node_facets_off[node]; q < m.h_node_facets_off[node + 1] && inner < 0; ++q)
+    {
+      const int32_t f = m.h_node_facets[q];
+      if (facet_type[f] == EQLB_FACET_INTERNAL)
+        inner = (m.h_facet_nodes[2 * (size_t)f] == node) ? m.h_facet_nodes[2 * (size_t)f + 1]
+                                                         : m.h_facet_nodes[2 * (size_t)f];
+    }
+    if (inner < 0)
+      continue;
+    std::vector<int32_t> members{inner};
+    for (int32_t q = m.h_node_cells_off[inner]; q < m.h_node_cells_off[inner + 1]; ++q)
+      for (int v = 0; v < 3; ++v)
+      {
+        const int32_t pnt = m.h_cell_nodes[3 * (size_t)m.h_node_cells[q] + v];
+        if (cnt[pnt] == 4 && m.h_node_ncells[pnt] == 2
+            && std::find(members.begin(), members.end(), pnt) == members.end())
+          members.push_back(pnt);
+      }
+    if (members.size() < 2)
+      continue;
+    for (int32_t nd : members)
+    {
+      if (group[nd] >= 0 || (node_mask && !node_mask[nd]))
+        return fail(EQLB_ERR_UNSUPPORTED,
+                    "Incompatible mesh! To many patches with 2 cells on neumann boundary.");
+      group[nd] = ngroups;
+      ws[nd] = (nd == inner) ? 2 : 1;
+    }
+    ++ngroups;
+    any = true;
+  }
+  // order independence: the cells of a group's internal patch touch no node of another group
+  for (int32_t node = 0; node < nn && any; ++node)
+    if (ws[node] == 2)
+      for (int32_t q = m.h_node_cells_off[node]; q < m.h_node_cells_off[node + 1]; ++q)
+        for (int v = 0; v < 3; ++v)
+        {
+          const int32_t nd = m.h_cell_nodes[3 * (size_t)m.h_node_cells[q] + v];
+          if (group[nd] >= 0 && group[nd] != group[node])
+            return fail(EQLB_ERR_UNSUPPORTED, "overlapping groups of boundary patches (stress equilibration)");
+        }
+  return EQLB_OK;
+}
+
 // Recursive coordinate bisection of the cell centroids into chunks of exactly `tc` cells (the last
 // one may be short): compact tiles keep the share of rim patches, which are solved by every tile
 // they touch, small.
@@ -259,7 +335,6 @@ int eqlb_mesh_create(int32_t nnodes, int32_t ncells, int32_t nfacets, const doub
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_mesh_create: null or empty input");
   if (eqlb_device_count() < 1)
     return fail(EQLB_ERR_DEVICE, "eqlb_mesh_create: no HIP device available");
-  (void)node_cells;
   eqlb_mesh* m = new eqlb_mesh();
   eqlb::DeviceMesh& d = m->m;
   d.nnodes = nnodes;
@@ -275,6 +350,11 @@ int eqlb_mesh_create(int32_t nnodes, int32_t ncells, int32_t nfacets, const doub
   }
   d.h_x.assign(x, x + (size_t)nnodes * 3);
   d.h_cell_nodes.assign(cell_nodes, cell_nodes + (size_t)ncells * 3);
+  d.h_facet_nodes.assign(facet_nodes, facet_nodes + (size_t)nfacets * 2);
+  d.h_node_facets_off.assign(node_facets_offsets, node_facets_offsets + (size_t)nnodes + 1);
+  d.h_node_facets.assign(node_facets, node_facets + (size_t)node_facets_offsets[nnodes]);
+  d.h_node_cells_off.assign(node_cells_offsets, node_cells_offsets + (size_t)nnodes + 1);
+  d.h_node_cells.assign(node_cells, node_cells + (size_t)node_cells_offsets[nnodes]);
   int st = 0;
   st |= upload(&d.x, x, (size_t)nnodes * 3);
   st |= upload(&d.cell_nodes, cell_nodes, (size_t)ncells * 3);
@@ -522,6 +602,22 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
   a.node_facets = m.node_facets;
   a.facet_perm = m.facet_perm;
   a.facet_type = h->facet_type;
+  if (h->stress && h->k == 2 && h->stress_flux_bcs)
+  {
+    std::vector<int8_t> ws;
+    std::vector<int32_t> grp;
+    bool any = false;
+    const int stg = find_stress_groups(m, facet_type, node_mask, ws, grp, any);
+    if (stg)
+      return stg;
+    if (any)
+    {
+      if (upload(&h->node_ws, ws.data(), ws.size()) || upload(&h->node_group, grp.data(), grp.size()))
+        return EQLB_ERR_DEVICE;
+      a.node_ws = h->node_ws;
+      a.node_group = h->node_group;
+    }
+  }
   a.node_slot = h->node_slot;
   a.node_patch = h->node_patch;
   a.npatch_total = h->npatch_total;

@@ -24,6 +24,13 @@ constexpr uint32_t INFO_LOCAL_SHIFT = 8;
 
 // per-(rhs, patch) flags
 constexpr uint8_t PFLAG_INTERIOR = 1, PFLAG_BC0 = 2, PFLAG_BCN = 4;
+// grouped boundary patches of the stress path (se/reconstruction.hpp:170-234), in the flags of RHS 0:
+// WS_SKIP: two-cell patch of a group, no weak-symmetry step of its own; WS_GROUP: internal patch of a
+// group, its weak-symmetry step works on own rows + rows of the group's two-cell patches
+constexpr uint8_t PFLAG_WS_SKIP = 8, PFLAG_WS_GROUP = 16;
+// slot_info bits 8-10 (plain SoA): local vertex v of the cell belongs to a two-cell patch of the
+// lane's group -> its slot row is added to the stress coefficients (bit 8 + v)
+constexpr uint32_t INFO_GROUPROW_SHIFT = 8;
 
 constexpr int MAX_BINS = 5;          // lanes per patch P = 4, 8, 16, 32, 64
 constexpr int BIN_P[MAX_BINS] = {4, 8, 16, 32, 64};
@@ -40,6 +47,7 @@ struct DeviceMesh
   uint8_t* facet_perm = nullptr;
   // host copies needed for binning / tiling
   std::vector<int32_t> h_node_ncells, h_node_nfcts, h_cell_nodes;
+  std::vector<int32_t> h_facet_nodes, h_node_facets_off, h_node_facets, h_node_cells_off, h_node_cells;
   std::vector<double> h_x;
 };
 
@@ -114,6 +122,10 @@ struct BuildArgs
   uint32_t* slot_info;
   uint8_t* pn;
   uint8_t* pflag;
+  // grouped stress patches (nullptr: none): per node 0 / 1 (two-cell member) / 2 (internal patch of
+  // a group) and the group id
+  const int8_t* node_ws;
+  const int32_t* node_group;
   // instance mode (tiled SoA): thread i builds the patch of node inst_node[i] at slot inst_slot[i]
   // as patch i of tile inst_tile[i]; nullptr: one patch per node (node_slot / node_patch)
   int64_t ninst;
@@ -198,6 +210,8 @@ struct eqlb_se
   // device
   double* tables = nullptr;
   int8_t* facet_type = nullptr;     // [nrhs][nfacets]
+  int8_t* node_ws = nullptr;        // grouped stress patches (stress && k == 2 && groups exist)
+  int32_t* node_group = nullptr;
   double* bvals = nullptr;          // [nrhs][ncells*nrt] global boundary DOFs (nullptr: homogeneous)
   int64_t* node_slot = nullptr;     // [nnodes] first slot of the node's patch or -1
   int64_t* node_patch = nullptr;    // [nnodes] patch index or -1

@@ -44,10 +44,22 @@ __global__ void __launch_bounds__(256) k_build_patches(BuildArgs a)
   const int32_t node = inst ? a.inst_node[tid_g] : (int32_t)tid_g;
   const int32_t tile = inst ? a.inst_tile[tid_g] : -1;
   // tiled SoA: 1 + local index of an owned cell in the upper bits of the descriptor
+  const int ws_kind = (a.node_ws && !inst) ? a.node_ws[node] : 0;
   auto local_bits = [&](int32_t c) -> uint32_t {
-    if (!inst || a.cell_tile[c] != tile)
+    if (inst)
+      return (a.cell_tile[c] != tile) ? 0u
+                                      : (uint32_t)(a.cell_pos[c] - tile * a.tile_cells + 1) << INFO_LOCAL_SHIFT;
+    if (ws_kind != 2)
       return 0u;
-    return (uint32_t)(a.cell_pos[c] - tile * a.tile_cells + 1) << INFO_LOCAL_SHIFT;
+    // internal patch of a group: mark the vertices of the cell that are two-cell members of it
+    uint32_t bits = 0u;
+    for (int v = 0; v < 3; ++v)
+    {
+      const int32_t nd = a.cell_nodes[3 * (int64_t)c + v];
+      if (nd != node && a.node_ws[nd] == 1 && a.node_group[nd] == a.node_group[node])
+        bits |= 1u << (INFO_GROUPROW_SHIFT + v);
+    }
+    return bits;
   };
   const int n = a.node_cells_off[node + 1] - a.node_cells_off[node];
   const int nf = a.node_facets_off[node + 1] - a.node_facets_off[node];
@@ -204,6 +216,10 @@ __global__ void __launch_bounds__(256) k_build_patches(BuildArgs a)
     for (int r = 0; r < a.nrhs; ++r)
     {
       uint8_t fl = interior ? PFLAG_INTERIOR : 0;
+      if (r == 0 && ws_kind == 1)
+        fl |= PFLAG_WS_SKIP;
+      if (r == 0 && ws_kind == 2)
+        fl |= PFLAG_WS_GROUP;
       if (!interior)
       {
         const int8_t* ft = a.facet_type + (int64_t)r * a.nfacets;

@@ -73,9 +73,13 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
   const int lane = tid & 63;
   const int sub = lane % P;
   const int64_t patch_local = ((int64_t)blockIdx.x * W::BLOCK + tid) / P;
-  const bool pvalid = patch_local < a.npatch;
   const int64_t slot = a.slot_offset + patch_local * P + sub;
   const int64_t patch = a.patch_offset + patch_local;
+  // two-cell patches of a group have no weak-symmetry step of their own (se/reconstruction.hpp:
+  // 181-229: it is imposed once, on the internal patch of the group)
+  const uint8_t flag0 = (patch_local < a.npatch) ? a.pflag[patch] : (uint8_t)PFLAG_INTERIOR;
+  const bool pvalid = patch_local < a.npatch && (flag0 & PFLAG_WS_SKIP) == 0;
+  const bool grouped = (flag0 & PFLAG_WS_GROUP) != 0;
   const int n = pvalid ? (int)a.pn[patch] : 0;
   const bool active = pvalid && sub < n;
   const int32_t cell = active ? a.slot_cell[slot] : 0;
@@ -99,9 +103,8 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
   const double sgn = (detJ > 0.0) ? 1.0 : -1.0;
   const double pf_m = (fm == 1) ? sgn : -sgn, pf_p = (fp == 1) ? sgn : -sgn;
 
-  const uint8_t flag0 = pvalid ? a.pflag[patch] : (uint8_t)PFLAG_INTERIOR;
   const uint8_t flag1 = pvalid ? a.pflag[a.npatch_total + patch] : (uint8_t)PFLAG_INTERIOR;
-  const bool interior = (flag0 & PFLAG_INTERIOR) != 0;
+  const bool interior = !pvalid || (flag0 & PFLAG_INTERIOR) != 0;
   const int nf = interior ? n : n + 1;
   const int nn = (n > 0) ? n : 1;
   const int fi_p = interior ? ((sub + 1 < nn) ? sub + 1 : 0) : sub + 1;
@@ -163,10 +166,23 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
   {
     srow[0] = a.out + (((int64_t)0 * a.ncells + cell) * 3 + ln) * NRT;
     srow[1] = a.out + (((int64_t)1 * a.ncells + cell) * 3 + ln) * NRT;
+    // grouped patches (modified_patch, se/solve_patch_weaksym.hpp:100-131): the stress accumulated by
+    // the group so far = own rows + the rows of the group's two-cell patches on this cell
+    const uint32_t grows = grouped ? ((info >> INFO_GROUPROW_SHIFT) & 7u) : 0u;
 #pragma unroll
     for (int i = 0; i < NRT; ++i)
     {
-      const double c0 = srow[0][i], c1 = srow[1][i];
+      double c0 = srow[0][i], c1 = srow[1][i];
+      if (grows)
+      {
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+          if (grows & (1u << v))
+          {
+            c0 += a.out[(((int64_t)0 * a.ncells + cell) * 3 + v) * NRT + i];
+            c1 += a.out[(((int64_t)1 * a.ncells + cell) * 3 + v) * NRT + i];
+          }
+      }
       const double w0 = c0 * J[1][0] - c1 * J[0][0], w1 = c0 * J[1][1] - c1 * J[0][1];
 #pragma unroll
       for (int j = 0; j < 3; ++j)

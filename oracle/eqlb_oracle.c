@@ -1449,7 +1449,7 @@ static int lu_solve(double* M, int ld, int n, double* b)
  * Requires equilibrate_patch to have run for this patch (coefficients of rows 0, 1, mapping
  * data, and - without flux BCs - the Cholesky factor of A). */
 static int impose_weak_symmetry(patch_t* p, pdata_t* d, const oracle_tables_t* tab,
-                                double* flux_hdiv)
+                                double* flux_hdiv, int modified_patch)
 {
   const int k = p->k, n = p->ncells, ndofs = p->ndofs, nh = d->nh, dm = d->dim_max;
   const int gdim = 2;
@@ -1481,10 +1481,18 @@ static int impose_weak_symmetry(patch_t* p, pdata_t* d, const oracle_tables_t* t
       if (types[i] == PT_ESSNT_DUAL || types[i] == PT_MIXED)
         requires_bcs = 1;
     }
-  /* stress coefficients = patch-local result of steps 1+2 :134-142 */
+  /* stress coefficients = patch-local result of steps 1+2 :134-142; grouped patches
+   * (modified_patch, :100-131): the values accumulated in the global stress so far */
   for (int r = 0; r < gdim; ++r)
     for (int a = 1; a <= n; ++a)
-      memcpy(d->cstress + ((size_t)(a - 1) * gdim + r) * ndofs, &COEF(p, d, r, a - 1, 0), sizeof(double) * ndofs);
+    {
+      if (modified_patch)
+        memcpy(d->cstress + ((size_t)(a - 1) * gdim + r) * ndofs,
+               flux_hdiv + ((size_t)r * ncells_mesh + p->cells[a]) * ndofs, sizeof(double) * ndofs);
+      else
+        memcpy(d->cstress + ((size_t)(a - 1) * gdim + r) * ndofs, &COEF(p, d, r, a - 1, 0),
+               sizeof(double) * ndofs);
+    }
   memset(d->bmarkers2, 0, 2 * dm);
   if (on_boundary)
     for (int i = 0; i < gdim; ++i)
@@ -1852,9 +1860,9 @@ int oracle_se_reconstruct(const oracle_mesh_t* mesh, const oracle_tables_t* tab,
                              flux_hdiv, node_begin, node_end, 0);
 }
 
-/* se::reconstruction with reconstruct_stress = true, loop over "all other patches"
- * (se/reconstruction.hpp:237-270); the grouped boundary patches of :170-234 (only with flux BCs
- * on the stress and RT_2) are not restated. */
+/* se::reconstruction with reconstruct_stress = true: grouped boundary patches
+ * (se/reconstruction.hpp:170-234, only with flux BCs on the stress and RT_2), then "all other
+ * patches" (:237-270). */
 int oracle_se_reconstruct_stress(const oracle_mesh_t* mesh, const oracle_tables_t* tab, int nrhs,
                                  const int8_t* facet_type, const double* boundary_values,
                                  const double* flux_dg, const double* rhs_dg, double* flux_hdiv,
@@ -1880,9 +1888,90 @@ static int se_reconstruct_impl(const oracle_mesh_t* mesh, const oracle_tables_t*
   pdata_t d;
   patch_alloc(&p, &d, mesh, tab, nrhs, facet_type);
   int status = 0;
-  /* se/reconstruction.hpp:286-313 */
+  const int nn = mesh->nnodes;
+  uint8_t* perform = (uint8_t*)malloc((size_t)nn);
+  memset(perform, 1, (size_t)nn);
+  /* grouped boundary patches, se/reconstruction.hpp:170-234 (RT_2 only): a node whose two boundary
+   * facets carry flux BCs on both stress rows (base/BoundaryData.cpp:611-631) and that has only two
+   * cells is equilibrated together with the adjacent internal patch (se/Patch.cpp:60-104,762-784);
+   * the weak symmetry is imposed once, on the internal patch, with the stress accumulated so far */
+  if (stress && tab->k == 2)
+  {
+    int8_t* on_bnd = (int8_t*)calloc((size_t)nn, 1);
+    for (int r = 0; r < 2; ++r)
+      for (int32_t f = 0; f < mesh->nfacets; ++f)
+        if (facet_type[(size_t)r * mesh->nfacets + f] == FT_ESSNT_DUAL)
+        {
+          on_bnd[mesh->facet_nodes[2 * (size_t)f]] += 1;
+          on_bnd[mesh->facet_nodes[2 * (size_t)f + 1]] += 1;
+        }
+    for (int i = 0; i < nn; ++i)
+      on_bnd[i] = (on_bnd[i] == 4);
+    int32_t group[64];
+    for (int32_t node = node_begin; node < node_end; ++node)
+    {
+      if (!(on_bnd[node] && perform[node]))
+        continue;
+      if (mesh->node_cells_off[node + 1] - mesh->node_cells_off[node] != 2)
+        continue;
+      /* adjacent internal patch: other node of the first internal facet of the node */
+      int32_t inner = -1;
+      for (int32_t q = mesh->node_facets_off[node]; q < mesh->node_facets_off[node + 1]; ++q)
+      {
+        const int32_t f = mesh->node_facets[q];
+        if (facet_type[f] == FT_INTERNAL)
+        {
+          const int32_t* fn = mesh->facet_nodes + 2 * (size_t)f;
+          inner = (fn[0] == node) ? fn[1] : fn[0];
+          break;
+        }
+      }
+      int ng = 0;
+      group[ng++] = inner;
+      for (int32_t q = mesh->node_cells_off[inner]; q < mesh->node_cells_off[inner + 1]; ++q)
+      {
+        const int32_t* cn = mesh->cell_nodes + 3 * (size_t)mesh->node_cells[q];
+        for (int v = 0; v < 3; ++v)
+        {
+          const int32_t pnt = cn[v];
+          if (!on_bnd[pnt])
+            continue;
+          int seen = 0;
+          for (int g = 0; g < ng; ++g)
+            seen |= (group[g] == pnt);
+          if (!seen && mesh->node_cells_off[pnt + 1] - mesh->node_cells_off[pnt] == 2 && ng < 64)
+            group[ng++] = pnt;
+        }
+      }
+      if (ng < 2)
+        continue;
+      for (int g = ng - 1; g >= 0; --g)
+      {
+        const int32_t node_i = group[g];
+        if (!perform[node_i])
+        {
+          status = -5; /* "Incompatible mesh! To many patches with 2 cells on neumann boundary." */
+          continue;
+        }
+        perform[node_i] = 0;
+        create_subdofmap(&p, node_i);
+        set_fctdofs_dg(&p, tab);
+        const int st = equilibrate_patch(&p, &d, tab, boundary_values, flux_dg, rhs_dg, flux_hdiv, NULL,
+                                         NULL, NULL);
+        if (st)
+          status = st;
+      }
+      const int st = impose_weak_symmetry(&p, &d, tab, flux_hdiv, 1);
+      if (st)
+        status = st;
+    }
+    free(on_bnd);
+  }
+  /* se/reconstruction.hpp:237-270 / 286-313: all other patches */
   for (int32_t node = node_begin; node < node_end; ++node)
   {
+    if (!perform[node])
+      continue;
     create_subdofmap(&p, node);
     set_fctdofs_dg(&p, tab);
     int st = equilibrate_patch(&p, &d, tab, boundary_values, flux_dg, rhs_dg, flux_hdiv, NULL,
@@ -1891,11 +1980,12 @@ static int se_reconstruct_impl(const oracle_mesh_t* mesh, const oracle_tables_t*
       status = st;
     if (stress)
     {
-      st = impose_weak_symmetry(&p, &d, tab, flux_hdiv);
+      st = impose_weak_symmetry(&p, &d, tab, flux_hdiv, 0);
       if (st)
         status = st;
     }
   }
+  free(perform);
   patch_free(&p, &d);
   return status;
 }

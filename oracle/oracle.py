@@ -121,6 +121,8 @@ def se_reconstruct(mesh, k, facet_type, flux_dg, rhs_dg, boundary_values=None, d
         raise RuntimeError("Stress equilibration: Specify all rows of stress tensor / RT_k with k>1")
     if st == -1:
         raise RuntimeError("Patch with only one cell")  # se/Patch.cpp:353-359
+    if st == -5:  # se/reconstruction.hpp:195-197
+        raise RuntimeError("Incompatible mesh! To many patches with 2 cells on neumann boundary.")
     if st != 0:
         raise RuntimeError(f"oracle failed with status {st}")
     return flux_hdiv

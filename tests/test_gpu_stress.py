@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("k,bc", [(2, "dirichlet"), (3, "dirichlet"), (3, "neumann_lt"),
-                                  (2, "neumann_bottom"), (3, "neumann_bottom")])
+                                  (2, "neumann_bottom"), (3, "neumann_bottom"), (2, "neumann_lt")])
 def test_stress_matches_oracle(oracle_mod, k, bc):
     from dolfinx_eqlb_amd import cpp
     mesh, ft, G, f = stress_case(7, k, bc)
@@ -47,3 +47,21 @@ def test_stress_high_valence(oracle_mod, k, ns):
     x = eq.equilibrate_host(G, f)
     ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f, stress=True)
     assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
+def test_stress_grouped_boundary_patches_all_neumann(oracle_mod):
+    """RT_2, flux BCs on the whole boundary: all four corner nodes (two cells each) are grouped with
+    their adjacent internal patches (se/reconstruction.hpp:170-234)."""
+    from dolfinx_eqlb_amd import cpp
+    from dolfinx_eqlb_amd.mesh import create_unit_square
+    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_stress_data
+    k = 2
+    mesh = create_unit_square(5, shuffle_seed=6, perturb=0.2)
+    ft = np.repeat(facet_types(mesh, lambda x: np.ones(len(x), dtype=bool)), 2, axis=0)
+    G, f = make_compatible_stress_data(mesh, k, ft)
+    ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f, stress=True)
+    eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(mesh), k, 2, reconstruct_stress=True)
+    eq.set_boundary(ft)
+    x = eq.equilibrate_host(G, f)
+    assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max()
+    assert np.abs(asym_moments(mesh, k, x)[1]).max() < 1e-11

@@ -50,8 +50,10 @@ def stress_case(n, k, bc, shuffle=5):
 
 
 @pytest.mark.parametrize("k,bc", [(2, "dirichlet"), (3, "dirichlet"), (3, "neumann_lt"), (3, "neumann_bottom"),
-                                  (2, "neumann_bottom")])
+                                  (2, "neumann_bottom"), (2, "neumann_lt")])
 def test_stress_conditions(oracle_mod, k, bc):
+    """(2, neumann_lt): the corner node between the two flux-BC sides has two cells -> grouped with
+    the adjacent internal patch (se/reconstruction.hpp:170-234)."""
     mesh, ft, G, f = stress_case(5, k, bc)
     x0 = oracle_mod.se_reconstruct(mesh, k, ft, G, f)
     xs = oracle_mod.se_reconstruct(mesh, k, ft, G, f, stress=True)
