@@ -512,9 +512,6 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
     const size_t nb = (size_t)h->nrhs * m.ncells * h->nrt;
     for (size_t i = 0; i < nb && !inhomogeneous; ++i)
       inhomogeneous = (boundary_values[i] != 0.0);
-    if (inhomogeneous && h->stress)
-      return fail(EQLB_ERR_UNSUPPORTED,
-                  "inhomogeneous flux BCs with stress equilibration are not in this build");
   }
   h->stress_flux_bcs = false;
   if (h->stress)

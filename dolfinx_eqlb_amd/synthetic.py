@@ -76,8 +76,9 @@ def boundary_dofs_from_field(mesh, k, ft_row, w):
     return out
 
 
-def neumann_hat_moments(mesh, ft_row, w):
-    """r_a = int_{Gamma_N} hat_a (w . n_out) ds for all nodes (compatibility of Neumann data)."""
+def neumann_hat_moments(mesh, ft_row, w, weight=None):
+    """r_a = int_{Gamma_N} hat_a (w . n_out) [weight(x, y)] ds for all nodes (compatibility of
+    Neumann data; with a weight x or y: the moment balance of stress rows)."""
     from .elmtlib import e_raviart_thomas as ert
     from .elmtlib.quadrature import make_quadrature_interval
     r = np.zeros(mesh.nnodes)
@@ -97,6 +98,8 @@ def neumann_hat_moments(mesh, ft_row, w):
         wx, wy = w(xq[..., 0], xq[..., 1])
         pb = np.einsum("cXd,cqd->cqX", K[sel], np.stack([wx, wy], axis=-1)) * detJ[sel][:, None, None]
         dens = (pb @ np.array(ert.FACET_NORMALS[f], dtype=float)) * (np.sign(detJ[sel]) * pfo[f])[:, None]
+        if weight is not None:
+            dens = dens * weight(xq[..., 0], xq[..., 1])
         hv = hat.tabulate(pts)[0]  # [q, n]
         loc = np.einsum("cq,q,qn->cn", dens, wq, hv)
         np.add.at(r, mesh.cell_nodes[cells[sel]].ravel(), loc.ravel())
@@ -211,19 +214,23 @@ def compatibility_residual(mesh, k, facet_type, flux_dg, rhs_dg, degree_dg=None)
     return float(np.max(np.abs(r[~fixed]))) if (~fixed).any() else 0.0
 
 
-def make_compatible_stress_data(mesh, k, facet_type, seed=20241003):
+def make_compatible_stress_data(mesh, k, facet_type, seed=20241003, neumann_flux=None):
     """Two rows (G_r, f_r) of a synthetic stress problem that satisfy, for every free node a,
     the force balance of each row, (f_r, hat_a) + (G_r, grad hat_a) = 0, AND the moment balance
     (f_0, hat_a y) + (G_0, grad(hat_a y)) - (f_1, hat_a x) - (G_1, grad(hat_a x)) = 0
     (what a P_k Galerkin elasticity solution, k >= 2, provides through the test functions
     hat_a (y, -x)); the latter makes the weak-symmetry patch problems consistent.
     Corrections: f_r -= c_r in P1, G += e [[0,1],[-1,0]] with e in P1 (sparse direct solve,
-    small meshes only).  Returns (flux_dg [2, ncells*nd*2], rhs_dg [2, ncells*nd])."""
+    small meshes only).  neumann_flux = [w_0, w_1]: prescribed tractions t_r = w_r . n on the flux-BC
+    facets (both balances then carry the boundary terms).
+    Returns (flux_dg [2, ncells*nd*2], rhs_dg [2, ncells*nd])."""
     if k < 2:
         raise RuntimeError("Stress equilibration: RT_k with k>1 required!")
     deg = k - 1
     ft = np.asarray(facet_type).reshape(-1, mesh.nfacets)
-    data = [make_compatible_data(mesh, k, ft[r:r + 1], seed=seed + 17 * r) for r in range(2)]
+    data = [make_compatible_data(mesh, k, ft[r:r + 1], seed=seed + 17 * r,
+                                 neumann_flux=None if neumann_flux is None else neumann_flux[r])
+            for r in range(2)]
     dg = Lagrange(deg)
     nd = dg.ndofs
     G = np.stack([d[0].reshape(mesh.ncells, nd, 2) for d in data])
@@ -265,6 +272,10 @@ def make_compatible_stress_data(mesh, k, facet_type, seed=20241003):
         + np.einsum("cq,cqd,cnd->cn", w, Gq[0] * Y[..., None] - Gq[1] * X[..., None], ghat) \
         + np.einsum("cq,cq,qn->cn", w, Gq[0][..., 1] - Gq[1][..., 0], hv)
     R_rot = assemble_vec(r_rot)
+    if neumann_flux is not None:
+        # boundary part of the moment balance: - int hat_a (y t_0 - x t_1)
+        R_rot -= neumann_hat_moments(mesh, ft[0], neumann_flux[0], weight=lambda x, y: y)
+        R_rot += neumann_hat_moments(mesh, ft[1], neumann_flux[1], weight=lambda x, y: x)
     # blocks of the 3-field system, unknowns (c0, c1, e), equations (R0, R1, Rrot) = 0
     Mh = assemble_mat(np.einsum("cq,qn,qm->cnm", w, hv, hv))                      # (hat_b, hat_a)
     My = assemble_mat(np.einsum("cq,cq,qn,qm->cnm", w, Y, hv, hv))                # (hat_b, hat_a y)

@@ -115,7 +115,8 @@ int eqlb_se_set_option(eqlb_se_t* handle, const char* key, int32_t value);
  *                    int (detJ K g).N_f s^j on the flux-BC facets, zero elsewhere), or NULL for
  *                    homogeneous flux BCs.  The per-patch values hat_a * g of
  *                    BoundaryData::calculate_patch_bc (base/BoundaryData.cpp:687-745) are formed
- *                    in the kernel.  Not combined with stress equilibration in this build.
+ *                    in the kernel.  With stress equilibration the rows carry the tractions; the
+ *                    weak-symmetry corrections have zero normal flux on those facets.
  *   node_mask        [nnodes] uint8 or NULL: equilibrate only patches of nodes with mask != 0
  *                    (node ownership of a partitioned run; the reference loops
  *                    index_map(0)->size_local() owned nodes, se/reconstruction.hpp:90,286).

@@ -65,3 +65,34 @@ def test_stress_grouped_boundary_patches_all_neumann(oracle_mod):
     x = eq.equilibrate_host(G, f)
     assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max()
     assert np.abs(asym_moments(mesh, k, x)[1]).max() < 1e-11
+
+
+@pytest.mark.parametrize("k,bc", [(2, "neumann_bottom"), (3, "neumann_lt"), (2, "neumann_lt")])
+def test_stress_with_inhomogeneous_tractions(oracle_mod, k, bc):
+    """Prescribed tractions t_r = w_r . n on the flux-BC sides (both stress rows), incl. the grouped
+    corner patches for (2, neumann_lt); data balanced in force and moment."""
+    from cases import BCS
+    from dolfinx_eqlb_amd import cpp
+    from dolfinx_eqlb_amd.mesh import create_unit_square
+    from dolfinx_eqlb_amd.synthetic import (boundary_dofs_from_field, facet_types,
+                                            make_compatible_stress_data)
+
+    def w0(x, y):
+        return 1.0 + 0.5 * x - 0.3 * y, -0.7 + 0.2 * x + 0.4 * y
+
+    def w1(x, y):
+        return -0.4 + 0.1 * x + 0.6 * y, 0.9 - 0.5 * x + 0.2 * y
+    mesh = create_unit_square(6, shuffle_seed=5, perturb=0.25)
+    ft = np.repeat(facet_types(mesh, BCS[bc]), 2, axis=0)
+    G, f = make_compatible_stress_data(mesh, k, ft, neumann_flux=[w0, w1])
+    bv = np.stack([boundary_dofs_from_field(mesh, k, ft[0], w0),
+                   boundary_dofs_from_field(mesh, k, ft[1], w1)])
+    ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f, boundary_values=bv, stress=True)
+    assert np.abs(asym_moments(mesh, k, ref)[1]).max() < 1e-11
+    eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(mesh), k, 2, reconstruct_stress=True)
+    eq.set_boundary(ft, boundary_values=bv)
+    x = eq.equilibrate_host(G, f)
+    assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max()
+    # the tractions are met: facet DOFs of sigma_eq + G on the flux-BC facets
+    sel = np.nonzero(bv[0] != 0)[0]
+    assert sel.size
