@@ -127,6 +127,14 @@ __device__ __forceinline__ double rsqrt_d(double x)
 }
 
 
+// row of the reduced tensors TE / WQ / VQ / WG: the six ordered pairs (fm, fp) of distinct local
+// facet ids of a patch cell x reversal flag of the minus facet (tools/gen_tables.py: combo)
+constexpr int NCOMBO = 12;
+__host__ __device__ constexpr int combo_index(int fm, int fp, bool rev)
+{
+  return (fm * 2 + ((fp < fm) ? fp : fp - 1)) * 2 + (rev ? 1 : 0);
+}
+
 // ---- compile-time sizes of a (K, DEG, P) patch kernel ------------------------------------------
 template <int K, int DEG, int P>
 struct Sizes
@@ -144,13 +152,13 @@ struct Sizes
   static constexpr int LDS_GROUP = TRI + DIMMAX; // doubles per patch for SOLVER 0
   // device table buffer: S | F | H | D | TE | WQ ; the kernel stages everything behind S in LDS
   static constexpr int NS = 3 * NRT * NRT, NF = 9 * ND * K, NHT = 3 * ND * NQ, NDT = 6 * ND * NQ;
-  static constexpr int NTET = 18 * 3 * NTE, NWQT = 18 * 3 * NH * NCOL;
+  static constexpr int NTET = NCOMBO * 3 * NTE, NWQT = NCOMBO * 3 * NH * NCOL;
   static constexpr int NHB = 9 * K * K;                           // flux-BC tensor HB
   static constexpr int NTAB = NF + NHT + NDT + NTET + NWQT + NHB;
-  static constexpr int NVT = 3 * NRT * 2, NVQT = 18 * 2 * NH * 3; // weak symmetry: V, VQ (behind HB)
+  static constexpr int NVT = 3 * NRT * 2, NVQT = NCOMBO * 2 * NH * 3; // weak symmetry: V, VQ (behind HB)
   static constexpr int OFF_TE = NS + NF + NHT + NDT, OFF_V = OFF_TE + NTET + NWQT + NHB, OFF_VQ = OFF_V + NVT;
   // constrained-minimisation (EV) mode: HG | WG behind VQ, staged in LDS behind HB
-  static constexpr int NHG = ND * NQ, NWG = 18 * NH * ND * 2, NEV = NHG + NWG;
+  static constexpr int NHG = ND * NQ, NWG = NCOMBO * NH * ND * 2, NEV = NHG + NWG;
   static constexpr int OFF_HG = OFF_VQ + NVQT;
   // workgroup size: as many waves as fit a 64 KiB LDS budget for the dense tiles (at least one)
   static constexpr int lds_doubles(int block, int solver, int mode = 0)

@@ -30,9 +30,9 @@ size_t table_doubles(int k, int deg)
   const int kb = k - 1, nadd = (k - 1) * (k - 2) / 2, ndiv = k * (k + 1) / 2 - 1;
   const int nh = 1 + 2 * kb + nadd, ncol = 2 * k + ndiv;
   return (size_t)3 * nrt * nrt + (size_t)9 * nd * k + (size_t)3 * nd * nq + (size_t)6 * nd * nq
-         + (size_t)18 * 3 * (nh * (nh + 1) / 2) + (size_t)18 * 3 * nh * ncol
-         + (size_t)9 * k * k + (size_t)3 * nrt * 2 + (size_t)18 * 2 * nh * 3
-         + (size_t)nd * nq + (size_t)18 * nh * nd * 2;
+         + (size_t)NCOMBO * 3 * (nh * (nh + 1) / 2) + (size_t)NCOMBO * 3 * nh * ncol
+         + (size_t)9 * k * k + (size_t)3 * nrt * 2 + (size_t)NCOMBO * 2 * nh * 3
+         + (size_t)nd * nq + (size_t)NCOMBO * nh * nd * 2;
 }
 
 template <int K, int DEG>
@@ -91,11 +91,11 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   double* sF = lds;             // [3][3][ND][K]
   double* sH = sF + Z::NF;      // [3][ND][NQ]
   double* sD = sH + Z::NHT;     // [3][ND][2][NQ]
-  double* sTE = sD + Z::NDT;    // [18][3][NTE]
-  double* sWQ = sTE + Z::NTET;  // [18][3][NH][NCOL]
+  double* sTE = sD + Z::NDT;    // [NCOMBO][3][NTE]
+  double* sWQ = sTE + Z::NTET;  // [NCOMBO][3][NH][NCOL]
   double* sHB = sWQ + Z::NWQT;                    // [3][3][K][K]
   double* sHG = sHB + Z::NHB;                     // MODE 1: [ND][NQ]
-  double* sWG = sHG + Z::NHG;                     // MODE 1: [18][NH][ND][2]
+  double* sWG = sHG + Z::NHG;                     // MODE 1: [NCOMBO][NH][ND][2]
   (void)sWG;
   double* sA = sHB + Z::NHB + (MODE ? Z::NEV : 0); // SOLVER 0: per-group tiles
   (void)sA;
@@ -131,7 +131,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   const int fm = (info >> INFO_FM_SHIFT) & 3, fp = (info >> INFO_FP_SHIFT) & 3;
   const int ln = (info >> INFO_LN_SHIFT) & 3;
   const bool rev_m = (info & INFO_REV_M) != 0, rev_p = (info & INFO_REV_P) != 0;
-  const int ci = (fm * 3 + fp) * 2 + (rev_m ? 1 : 0); // row of the reduced tensors
+  const int ci = active ? combo_index(fm, fp, rev_m) : 0; // row of the reduced tensors
 
   const int r = a.rhs; // one right-hand side per launch
 

@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
   const int fm = (info >> INFO_FM_SHIFT) & 3, fp = (info >> INFO_FP_SHIFT) & 3;
   const int ln = (info >> INFO_LN_SHIFT) & 3;
   const bool rev_m = (info & INFO_REV_M) != 0;
-  const int ci = (fm * 3 + fp) * 2 + (rev_m ? 1 : 0);
+  const int ci = active ? combo_index(fm, fp, rev_m) : 0;
 
   double J[2][2] = {{1.0, 0.0}, {0.0, 1.0}};
   if (active)
@@ -733,7 +733,7 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
   const int fm = (info >> INFO_FM_SHIFT) & 3, fp = (info >> INFO_FP_SHIFT) & 3;
   const int ln = (info >> INFO_LN_SHIFT) & 3;
   const bool rev_m = (info & INFO_REV_M) != 0;
-  const int ci = (fm * 3 + fp) * 2 + (rev_m ? 1 : 0);
+  const int ci = active ? combo_index(fm, fp, rev_m) : 0;
 
   double J[2][2] = {{1.0, 0.0}, {0.0, 1.0}};
   if (active)

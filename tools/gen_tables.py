@@ -33,6 +33,12 @@ from dolfinx_eqlb_amd.elmtlib import e_raviart_thomas as ert  # noqa: E402
 from dolfinx_eqlb_amd.elmtlib.lagrange import Lagrange  # noqa: E402
 
 PAIRS = [(1, 0), (2, 1), (3, 2), (2, 0), (3, 1), (3, 0)]  # (k, degree of DG data)
+NCOMBO = 12  # (fm, fp, rev) combinations with fm != fp
+
+
+def combo(fm, fp, rev):
+    """Row of the reduced tensors: the six ordered pairs of distinct local facet ids x reversal."""
+    return (fm * 2 + (fp if fp < fm else fp - 1)) * 2 + rev
 
 
 def tables_exact(k, deg):
@@ -95,14 +101,14 @@ def tables_exact(k, deg):
     WGF = [[[[P.integrate_triangle(P.mul(P.mul(hat.basis[n], dg.basis[d]), rt.basis[i][c]))
               for c in range(2)] for d in range(nd)] for i in range(nrt)] for n in range(3)]
     nh = 1 + 2 * (k - 1) + (k - 1) * (k - 2) // 2
-    WG = [[[[Fraction(0)] * 2 for _ in range(nd)] for _ in range(nh)] for _ in range(18)]
+    WG = [[[[Fraction(0)] * 2 for _ in range(nd)] for _ in range(nh)] for _ in range(NCOMBO)]
     for fm in range(3):
         for fp in range(3):
             if fm == fp:
                 continue
             ln = 3 - fm - fp
             for rev in range(2):
-                ci = (fm * 3 + fp) * 2 + rev
+                ci = combo(fm, fp, rev)
                 idx, d0, Q, ny, nh_ = _local_maps(k, B, fm, fp, rev)
                 for h in range(nh):
                     for d in range(nd):
@@ -151,13 +157,13 @@ def _local_maps(k, B, fm, fp, rev):
 def reduced_symmetry_tensor(k, V, B):
     zero = Fraction(0)
     nh = 1 + 2 * (k - 1) + (k - 1) * (k - 2) // 2
-    VQ = [[[[zero] * 3 for _ in range(nh)] for _ in range(2)] for _ in range(18)]
+    VQ = [[[[zero] * 3 for _ in range(nh)] for _ in range(2)] for _ in range(NCOMBO)]
     for fm in range(3):
         for fp in range(3):
             if fm == fp:
                 continue
             for rev in range(2):
-                ci = (fm * 3 + fp) * 2 + rev
+                ci = combo(fm, fp, rev)
                 idx, d0, Q, ny, nh_ = _local_maps(k, B, fm, fp, rev)
                 for X in range(2):
                     for h in range(nh):
@@ -187,8 +193,8 @@ def reduced_tensors(k, S, B):
     ncol = 2 * k + ndiv
     nte = nh * (nh + 1) // 2
     zero = Fraction(0)
-    TE = [[[zero] * nte for _ in range(3)] for _ in range(18)]
-    WQ = [[[[zero] * ncol for _ in range(nh)] for _ in range(3)] for _ in range(18)]
+    TE = [[[zero] * nte for _ in range(3)] for _ in range(NCOMBO)]
+    WQ = [[[[zero] * ncol for _ in range(nh)] for _ in range(3)] for _ in range(NCOMBO)]
     for fm in range(3):
         for fp in range(3):
             if fm == fp:
@@ -199,7 +205,7 @@ def reduced_tensors(k, S, B):
             sp = 1 if ert.FACET_NORMAL_IS_OUTWARD[fp] else -1
             d0 = [sm] * k + [sp] * k + [1] * nadd
             for rev in range(2):
-                ci = (fm * 3 + fp) * 2 + rev
+                ci = combo(fm, fp, rev)
                 Q = [[zero] * nh for _ in range(ny)]
                 for j in range(k):
                     for c in range(k):
@@ -275,13 +281,13 @@ def emit(path):
         arr("B", (k, k), t["B"])
         kb_, nadd_, ndiv_ = k - 1, (k - 1) * (k - 2) // 2, k * (k + 1) // 2 - 1
         nh_ = 1 + 2 * kb_ + nadd_
-        arr("TE", (18, 3, nh_ * (nh_ + 1) // 2), t["TE"])
-        arr("WQ", (18, 3, nh_, 2 * k + ndiv_), t["WQ"])
+        arr("TE", (NCOMBO, 3, nh_ * (nh_ + 1) // 2), t["TE"])
+        arr("WQ", (NCOMBO, 3, nh_, 2 * k + ndiv_), t["WQ"])
         arr("V", (3, nrt, 2), t["V"])
-        arr("VQ", (18, 2, nh_, 3), t["VQ"])
+        arr("VQ", (NCOMBO, 2, nh_, 3), t["VQ"])
         arr("HB", (3, 3, k, k), t["HB"])
         arr("HG", (nd, nq), t["HG"])
-        arr("WG", (18, nh_, nd, 2), t["WG"])
+        arr("WG", (NCOMBO, nh_, nd, 2), t["WG"])
         arr("DM", (nd, 2, nq), t["DM"])
         arr("GMI", (nq, nq), t["GMI"])
         arr("F0", (3, nd, k), t["F0"])
