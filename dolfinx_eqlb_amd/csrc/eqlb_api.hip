@@ -425,8 +425,10 @@ int eqlb_se_create(eqlb_mesh_t* mesh, int32_t k, int32_t degree_dg, int32_t nrhs
   }
   (void)estimate_korn;
   std::vector<double> tab;
-  if (eqlb::fill_tables_host(k, degree_dg, tab) != 0 || degree_dg != k - 1 || k > 3)
-    return fail(EQLB_ERR_UNSUPPORTED, "RT_%d with DG_%d data is not in this build", k, degree_dg);
+  if (eqlb::fill_tables_host(k, degree_dg, tab) != 0 || degree_dg != k - 1 || k > 4
+      || (k == 4 && reconstruct_stress))
+    return fail(EQLB_ERR_UNSUPPORTED, "RT_%d with DG_%d data%s is not in this build", k, degree_dg,
+                reconstruct_stress ? " (stress)" : "");
   eqlb_se* h = new eqlb_se();
   h->mesh = mesh;
   h->k = k;
@@ -435,6 +437,8 @@ int eqlb_se_create(eqlb_mesh_t* mesh, int32_t k, int32_t degree_dg, int32_t nrhs
   h->stress = reconstruct_stress ? 1 : 0;
   // default result path: tiled launch where it is the fastest (measured)
   h->scatter = EQLB_SCATTER_AUTO;
+  if (k == 4) // three interior unknowns per cell: the register solver condenses at most one
+    h->solver = EQLB_SOLVER_LDS_CHOLESKY;
   h->nrt = k * (k + 2);
   h->nd = (degree_dg + 1) * (degree_dg + 2) / 2;
   int st = upload(&h->tables, tab.data(), tab.size());
@@ -946,8 +950,8 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
       HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS], stream));
     if (ev_conf)
       eqlb::launch_ev_reduce(m, h->k, h->nrhs, h->ev_cell_dofs, h->ev_ndofs, h->slots, d_x, stream);
-    else
-      eqlb::launch_reduce_slots(h->nrt, m.ncells, h->nrhs, h->slots, d_x, stream);
+    else if (eqlb::launch_reduce_slots(h->nrt, m.ncells, h->nrhs, h->slots, d_x, stream))
+      return fail(EQLB_ERR_UNSUPPORTED, "slot reduction for %d DOFs per cell is not in this build", h->nrt);
     if (evs)
       HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS + 1], stream));
   }

@@ -162,8 +162,8 @@ void launch_ev_boundary_to_broken(const DeviceMesh& m, int k, int nrhs, const in
                                   hipStream_t stream);
 void launch_ev_reduce(const DeviceMesh& m, int k, int nrhs, const int32_t* cell_dofs, int64_t ndofs,
                       const double* slots, double* x, hipStream_t stream);
-void launch_reduce_slots(int nrt, int32_t ncells, int32_t nrhs, const double* slots, double* x,
-                         hipStream_t stream);
+int launch_reduce_slots(int nrt, int32_t ncells, int32_t nrhs, const double* slots, double* x,
+                        hipStream_t stream);
 int projection_matrix_host(int degree, int nq, const double* pts, const double* wts,
                            std::vector<double>& Pm);
 void launch_project_dg(int64_t ncells, int nd, int nq, int bs, const double* Pm, const double* qv,

@@ -61,6 +61,8 @@ int fill_tables_host(int k, int deg, std::vector<double>& out)
     fill_tables_t<2, 1>(out);
   else if (k == 3 && deg == 2)
     fill_tables_t<3, 2>(out);
+  else if (k == 4 && deg == 3)
+    fill_tables_t<4, 3>(out);
   else if (k == 2 && deg == 0)
     fill_tables_t<2, 0>(out);
   else if (k == 3 && deg == 1)
@@ -1424,8 +1426,8 @@ k_reduce_slots(int64_t ntotal, const double* __restrict__ slots, double* __restr
   x[e] += (s[0] + s[NRT]) + s[2 * NRT];
 }
 
-void launch_reduce_slots(int nrt, int32_t ncells, int32_t nrhs, const double* slots, double* x,
-                         hipStream_t stream)
+int launch_reduce_slots(int nrt, int32_t ncells, int32_t nrhs, const double* slots, double* x,
+                        hipStream_t stream)
 {
   const int64_t ntotal = (int64_t)nrhs * ncells * nrt;
   const int block = 256;
@@ -1436,6 +1438,11 @@ void launch_reduce_slots(int nrt, int32_t ncells, int32_t nrhs, const double* sl
     hipLaunchKernelGGL(k_reduce_slots<8>, dim3(grid), dim3(block), 0, stream, ntotal, slots, x);
   else if (nrt == 15)
     hipLaunchKernelGGL(k_reduce_slots<15>, dim3(grid), dim3(block), 0, stream, ntotal, slots, x);
+  else if (nrt == 24)
+    hipLaunchKernelGGL(k_reduce_slots<24>, dim3(grid), dim3(block), 0, stream, ntotal, slots, x);
+  else
+    return EQLB_ERR_UNSUPPORTED;
+  return 0;
 }
 
 // ---- dispatch -------------------------------------------------------------------------------------
@@ -1539,9 +1546,21 @@ int launch_se_patch_fused(int k, int deg, int scatter, const SeArgs& a, const Fu
   return EQLB_ERR_UNSUPPORTED;
 }
 
+// k = 4 (three interior unknowns per cell): dense LDS Cholesky only, patches of up to 8 facets
+static int launch_k4(int P, int solver, int scatter, const SeArgs& a, hipStream_t stream)
+{
+  if (solver != EQLB_SOLVER_LDS_CHOLESKY || (P != 4 && P != 8))
+    return EQLB_ERR_UNSUPPORTED;
+  if (scatter == EQLB_SCATTER_SLOTS)
+    return (P == 4) ? launch_t<4, 3, 4, 0, 0>(a, stream) : launch_t<4, 3, 8, 0, 0>(a, stream);
+  return (P == 4) ? launch_t<4, 3, 4, 0, 1>(a, stream) : launch_t<4, 3, 8, 0, 1>(a, stream);
+}
+
 int launch_se_patch(int k, int deg, int P, int solver, int scatter, const SeArgs& a,
                     hipStream_t stream)
 {
+  if (k == 4 && deg == 3)
+    return launch_k4(P, solver, scatter, a, stream);
   if (k == 1 && deg == 0)
     return launch_kd<1, 0>(P, solver, scatter, a, stream);
   if (k == 2 && deg == 1)

@@ -263,3 +263,19 @@ def test_geometry_scaling_and_offset(cpp, oracle_mod, scale, shift):
     for scatter in (0, 2):
         x, _ = _gpu(cpp, mesh, k, ft, G[None], f[None], scatter=scatter)
         assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("bc", ["dirichlet", "neumann_lt", "neumann_bottom"])
+def test_k4_matches_oracle(cpp, oracle_mod, bc):
+    """RT_4 (three interior unknowns per cell): dense LDS Cholesky path, patches of up to 8 facets
+    (the reference's tests go up to k = 4, python/test/unit/test_fluxeqlb_conditions.py)."""
+    k = 4
+    mesh, ft, G, f = make_case(5, k, bc)
+    ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f)
+    eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(mesh), k, 1)
+    eq.set_boundary(ft)
+    x = eq.equilibrate_host(G, f)
+    assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max()
+    from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
+    res, nrm = chk.divergence_residual(mesh, k, x[0], G[0], f[0])
+    assert res < 1e-10 * nrm and chk.check_jump_condition(mesh, k, x[0], G[0], atol=1e-9)

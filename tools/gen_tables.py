@@ -32,7 +32,7 @@ from dolfinx_eqlb_amd.elmtlib import polynomials as P  # noqa: E402
 from dolfinx_eqlb_amd.elmtlib import e_raviart_thomas as ert  # noqa: E402
 from dolfinx_eqlb_amd.elmtlib.lagrange import Lagrange  # noqa: E402
 
-PAIRS = [(1, 0), (2, 1), (3, 2), (2, 0), (3, 1), (3, 0)]  # (k, degree of DG data)
+PAIRS = [(1, 0), (2, 1), (3, 2), (4, 3), (2, 0), (3, 1), (3, 0)]  # (k, degree of DG data)
 NCOMBO = 12  # (fm, fp, rev) combinations with fm != fp
 
 
