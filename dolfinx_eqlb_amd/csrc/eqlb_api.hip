@@ -335,6 +335,37 @@ int eqlb_mesh_create(int32_t nnodes, int32_t ncells, int32_t nfacets, const doub
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_mesh_create: null or empty input");
   if (eqlb_device_count() < 1)
     return fail(EQLB_ERR_DEVICE, "eqlb_mesh_create: no HIP device available");
+  // The kernels index with these tables unchecked: a bad entry would fault on the device, so the
+  // connectivities are validated here (O(size) on the host, once per mesh).
+  {
+    auto csr_ok = [](const int32_t* off, int32_t n, const int32_t* val, int32_t bound) {
+      if (off[0] != 0)
+        return false;
+      for (int32_t i = 0; i < n; ++i)
+        if (off[i + 1] < off[i])
+          return false;
+      for (int32_t q = 0; q < off[n]; ++q)
+        if (val[q] < 0 || val[q] >= bound)
+          return false;
+      return true;
+    };
+    bool ok = true;
+    for (size_t i = 0; i < (size_t)ncells * 3 && ok; ++i)
+      ok = cell_nodes[i] >= 0 && cell_nodes[i] < nnodes && cell_facets[i] >= 0 && cell_facets[i] < nfacets
+           && facet_perm[i] <= 1;
+    for (size_t i = 0; i < (size_t)nfacets * 2 && ok; ++i)
+      ok = facet_nodes[i] >= 0 && facet_nodes[i] < nnodes;
+    ok = ok && csr_ok(facet_cells_offsets, nfacets, facet_cells, ncells)
+         && csr_ok(node_cells_offsets, nnodes, node_cells, ncells)
+         && csr_ok(node_facets_offsets, nnodes, node_facets, nfacets);
+    for (int32_t f = 0; f < nfacets && ok; ++f)
+    {
+      const int32_t nc = facet_cells_offsets[f + 1] - facet_cells_offsets[f];
+      ok = (nc == 1 || nc == 2);
+    }
+    if (!ok)
+      return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_mesh_create: inconsistent connectivity tables");
+  }
   eqlb_mesh* m = new eqlb_mesh();
   eqlb::DeviceMesh& d = m->m;
   d.nnodes = nnodes;
@@ -510,6 +541,9 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
   if (!h || !facet_type)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_set_boundary: null argument");
   const eqlb::DeviceMesh& m = h->mesh->m;
+  for (size_t i = 0; i < (size_t)h->nrhs * m.nfacets; ++i)
+    if (facet_type[i] < EQLB_FACET_INTERNAL || facet_type[i] > EQLB_FACET_ESSNT_DUAL)
+      return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_set_boundary: facet type %d out of range", (int)facet_type[i]);
   bool inhomogeneous = false;
   if (boundary_values)
   {

@@ -279,3 +279,21 @@ def test_k4_matches_oracle(cpp, oracle_mod, bc):
     from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
     res, nrm = chk.divergence_residual(mesh, k, x[0], G[0], f[0])
     assert res < 1e-10 * nrm and chk.check_jump_condition(mesh, k, x[0], G[0], atol=1e-9)
+
+
+def test_invalid_connectivity_is_refused(cpp):
+    """Bad index tables must be caught on the host (they would fault on the device)."""
+    import copy
+    from dolfinx_eqlb_amd.mesh import create_unit_square
+    from dolfinx_eqlb_amd.synthetic import facet_types
+    mesh = create_unit_square(3)
+    bad = copy.copy(mesh)
+    bad.cell_nodes = mesh.cell_nodes.copy()
+    bad.cell_nodes[5, 1] = mesh.nnodes + 7
+    with pytest.raises(RuntimeError, match="inconsistent connectivity"):
+        cpp.DeviceMesh(bad)
+    eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(mesh), 2, 1)
+    ft = facet_types(mesh, None)
+    ft[0, 3] = 7
+    with pytest.raises(RuntimeError, match="facet type"):
+        eq.set_boundary(ft)
