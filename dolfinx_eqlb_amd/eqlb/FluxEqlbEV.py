@@ -13,8 +13,8 @@ import numpy as np
 
 from .. import cpp
 from ..mesh import Mesh
-from .conforming import broken_to_conforming, conforming_dofmap
-from .FluxEqlbSE import fluxbc
+from .conforming import conforming_dofmap
+from .bcs import boundarydata, fluxbc
 
 
 class FluxEqlbEV:
@@ -48,25 +48,13 @@ class FluxEqlbEV:
         """FluxEqlbEV.py:136-165."""
         if self.n_fluxes != len(list_bfct_prime) or self.n_fluxes != len(list_bcs_flux):
             raise RuntimeError("Mismatching inputs!")
-        from ..synthetic import boundary_dofs_from_field
-        k = self.degree_flux
-        ft = np.zeros((self.n_fluxes, self.mesh.nfacets), dtype=np.int8)
-        bv = None
-        for i in range(self.n_fluxes):
-            ft[i, np.asarray(list_bfct_prime[i], dtype=np.int64)] = 1
-            for bc in list_bcs_flux[i]:
-                ft[i, bc.facets] = 2
-            for bc in list_bcs_flux[i]:
-                if bc.value is not None:
-                    if bv is None:
-                        bv = np.zeros_like(self.list_flux)
-                    row = np.zeros(self.mesh.nfacets, dtype=np.int8)
-                    row[bc.facets] = 2
-                    bv[i] += broken_to_conforming(
-                        self.mesh, k, boundary_dofs_from_field(self.mesh, k, row, bc.value))
-        self.facet_type = ft
-        self.boundary_values = bv
-        self._eq.set_boundary(ft, boundary_values=bv)
+        # boundary functions of the conforming flux space (FluxEqlbEV.py:153-165)
+        self.list_bfunctions = [np.zeros(self.ndofs) for _ in range(self.n_fluxes)]
+        bd = boundarydata(list_bcs_flux, self.list_bfunctions, (self.mesh, self.degree_flux), False,
+                          list_bfct_prime, self.equilibrate_stresses)
+        self.facet_type = bd.facet_type
+        self.boundary_values = bd.boundary_values
+        self._eq.set_boundary(bd.facet_type, boundary_values=bd.boundary_values)
         self.boundary_data = self._eq
 
     def equilibrate_fluxes(self):

@@ -14,22 +14,7 @@ from .. import cpp
 from ..mesh import Mesh
 
 
-class fluxbc:
-    """Flux boundary condition on a set of facets (stand-in for
-    python/dolfinx_eqlb/eqlb/bcs.py:25 `fluxbc`).
-
-    `value` is 0/None (homogeneous) or a callable (x, y) -> (w_x, w_y): the reconstructed flux
-    then satisfies sigma.n = w.n on the facets, with w.n interpolated into the facet DOFs of
-    RT_k exactly as BoundaryData does for a FluxBC that needs no projection
-    (base/BoundaryData.cpp:148-260)."""
-
-    def __init__(self, value, facets, V=None, requires_projection=False, quadrature_degree=None):
-        if value in (0, 0.0):
-            value = None
-        if value is not None and not callable(value):
-            raise NotImplementedError("flux BC values are 0 or a callable (x, y) -> (wx, wy)")
-        self.value = value
-        self.facets = np.asarray(facets, dtype=np.int32)
+from .bcs import boundarydata, fluxbc  # noqa: E402,F401  (fluxbc is re-exported from here)
 
 
 class FluxEqlbSE:
@@ -81,23 +66,13 @@ class FluxEqlbSE:
         list_bcs_flux[i]: flux BCs (FluxEqlbSE.py:118-147)."""
         if self.n_fluxes != len(list_bfct_prime) or self.n_fluxes != len(list_bcs_flux):
             raise RuntimeError("Mismatching inputs!")
-        from ..synthetic import boundary_dofs_from_field
-        ft = np.zeros((self.n_fluxes, self.mesh.nfacets), dtype=np.int8)
-        bv = None
-        for i in range(self.n_fluxes):
-            ft[i, np.asarray(list_bfct_prime[i], dtype=np.int64)] = 1
-            for bc in list_bcs_flux[i]:
-                ft[i, bc.facets] = 2
-            for bc in list_bcs_flux[i]:
-                if bc.value is not None:
-                    if bv is None:
-                        bv = np.zeros_like(self.list_flux)
-                    row = np.zeros(self.mesh.nfacets, dtype=np.int8)
-                    row[bc.facets] = 2
-                    bv[i] += boundary_dofs_from_field(self.mesh, self.degree_flux, row, bc.value)
-        self.facet_type = ft
-        self.boundary_values = bv
-        self._eq.set_boundary(ft, boundary_values=bv)
+        # boundary functions of the discontinuous hierarchic RT_k space (FluxEqlbSE.py:134-145)
+        self.list_bfunctions = [np.zeros(self.list_flux.shape[1]) for _ in range(self.n_fluxes)]
+        bd = boundarydata(list_bcs_flux, self.list_bfunctions, (self.mesh, self.degree_flux), True,
+                          list_bfct_prime, self.equilibrate_stresses)
+        self.facet_type = bd.facet_type
+        self.boundary_values = bd.boundary_values
+        self._eq.set_boundary(bd.facet_type, boundary_values=bd.boundary_values)
         self.boundary_data = self._eq
 
     def equilibrate_fluxes(self):

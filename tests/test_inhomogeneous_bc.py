@@ -92,3 +92,31 @@ def test_gpu_inhomogeneous_bc(oracle_mod, k, bc, solver):
     x = eq.equilibrate_host(G[None], f[None])[0]
     ref = oracle_mod.se_reconstruct(mesh, k, ft, G[None], f[None], boundary_values=bv[None])[0]
     assert np.abs(x - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 2])
+def test_class_api_with_inhomogeneous_fluxbc(oracle_mod, k):
+    """FluxEqlbSE / FluxEqlbEV with `fluxbc(value=callable, facets)` through `boundarydata`, the
+    reference's call sequence (FluxEqlbSE.py:118-174, bcs.py:25-217)."""
+    from dolfinx_eqlb_amd.eqlb import FluxEqlbEV, FluxEqlbSE, fluxbc
+    from dolfinx_eqlb_amd.eqlb.conforming import broken_to_conforming, conforming_dofmap
+    mesh, ft, G, f, bv, w = case(6, k, "neumann_lt")
+    bf = mesh.boundary_facets()
+    prime, dual = bf[ft[0][bf] == 1], bf[ft[0][bf] == 2]
+    se = FluxEqlbSE(k, mesh, [f], [G])
+    se.set_boundary_conditions([prime], [[fluxbc(w, dual)]])
+    assert np.allclose(se.list_bfunctions[0], bv)
+    se.equilibrate_fluxes()
+    ref = oracle_mod.se_reconstruct(mesh, k, ft, G[None], f[None], boundary_values=bv[None])[0]
+    assert np.abs(se.get_reconstructed_fluxes(0)[0] - ref).max() <= 1e-11 * np.abs(ref).max()
+    ev = FluxEqlbEV(k, mesh, [f], [G])
+    ev.set_boundary_conditions([prime], [[fluxbc(w, dual)]])
+    ev.equilibrate_fluxes()
+    cd, nd = conforming_dofmap(mesh, k)
+    bvc = broken_to_conforming(mesh, k, bv)
+    refe = oracle_mod.ev_reconstruct(mesh, k, ft, G[None], f[None], cd, nd, boundary_values=bvc[None])[0]
+    assert np.abs(ev.get_reconstructed_fluxes(0) - refe).max() <= 1e-11 * max(1.0, np.abs(refe).max())
+    with pytest.raises(RuntimeError, match="does not match"):
+        from dolfinx_eqlb_amd.eqlb import boundarydata
+        boundarydata([[]], [], (mesh, k), True, [prime], False)
