@@ -1,0 +1,107 @@
+"""Randomised parity: Delaunay triangulations of random point clouds (valence 3 ... ~10, arbitrary
+local vertex order), random flux-BC / Dirichlet patterns that differ between the right-hand sides
+(mixed patches, patches whose first facet changes type between RHS), against the oracle."""
+
+import numpy as np
+import pytest
+from scipy.spatial import Delaunay
+
+from dolfinx_eqlb_amd.eqlb.conforming import conforming_dofmap
+from dolfinx_eqlb_amd.mesh import create_mesh
+from dolfinx_eqlb_amd.synthetic import make_compatible_data
+
+
+def random_case(seed, k, nrhs):
+    rng = np.random.default_rng(seed)
+    for attempt in range(20):
+        npts = int(rng.integers(40, 120))
+        pts = rng.random((npts, 2))
+        # well-shaped hull: the corners and a few points on every side
+        side = np.linspace(0.0, 1.0, 7)[1:-1]
+        hull = np.concatenate([[[0, 0], [1, 0], [0, 1], [1, 1]],
+                               np.stack([side, 0 * side], 1), np.stack([side, 0 * side + 1], 1),
+                               np.stack([0 * side, side], 1), np.stack([0 * side + 1, side], 1)])
+        pts = np.concatenate([hull, 0.05 + 0.9 * pts])
+        tri = Delaunay(pts)
+        cells = tri.simplices.astype(np.int32)
+        # random local vertex order (reversed facets, detJ of both signs)
+        perm = np.array([[0, 1, 2], [1, 2, 0], [2, 0, 1], [0, 2, 1], [2, 1, 0], [1, 0, 2]])
+        cells = np.take_along_axis(cells, perm[rng.integers(0, 6, size=cells.shape[0])], axis=1)
+        mesh = create_mesh(pts, cells)
+        if np.diff(mesh.node_cells_offsets).min() >= 2:
+            break
+    else:
+        pytest.skip("no admissible random mesh")
+    bf = mesh.boundary_facets()
+    ft = np.zeros((nrhs, mesh.nfacets), dtype=np.int8)
+    for r in range(nrhs):
+        t = np.where(rng.random(bf.size) < 0.5, 2, 1).astype(np.int8)
+        t[rng.integers(0, bf.size)] = 1  # at least one primal-Dirichlet facet
+        ft[r, bf] = t
+    data = [make_compatible_data(mesh, k, ft[r:r + 1], seed=1000 * seed + r) for r in range(nrhs)]
+    return mesh, ft, np.stack([d[0] for d in data]), np.stack([d[1] for d in data])
+
+
+@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_oracle_random_meshes_satisfy_the_predicates(oracle_mod, seed, k):
+    from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
+    mesh, ft, G, f = random_case(seed, k, 2)
+    x = oracle_mod.se_reconstruct(mesh, k, ft, G, f)
+    for r in range(2):
+        res, nrm = chk.divergence_residual(mesh, k, x[r], G[r], f[r])
+        assert res < 1e-9 * nrm
+        assert chk.check_jump_condition(mesh, k, x[r], G[r], atol=1e-9)
+        assert chk.boundary_flux_residual(mesh, k, x[r], G[r], np.nonzero(ft[r] == 2)[0]) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_gpu_random_meshes(oracle_mod, seed, k):
+    from dolfinx_eqlb_amd import cpp
+    nrhs = 3
+    mesh, ft, G, f = random_case(seed, k, nrhs)
+    ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f)
+    dm = cpp.DeviceMesh(mesh)
+    for scatter, solver in ((2, 1), (0, 1), (0, 0)):
+        eq = cpp.SemiExplicitEquilibrator(dm, k, nrhs)
+        eq.set_option("solver", solver)
+        eq.set_option("scatter", scatter)
+        eq.set_boundary(ft)
+        x = eq.equilibrate_host(G, f)
+        assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max(), (scatter, solver)
+    cd, nd = conforming_dofmap(mesh, k)
+    refe = oracle_mod.ev_reconstruct(mesh, k, ft, G, f, cd, nd)
+    ev = cpp.ConstrainedMinEquilibrator(dm, k, nrhs)
+    ev.set_boundary(ft)
+    xe = ev.equilibrate_host(G, f)
+    assert np.abs(xe - refe).max() <= 1e-10 * max(1.0, np.abs(refe).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("k", [2, 3])
+def test_gpu_random_meshes_stress(oracle_mod, seed, k):
+    """Weak symmetry on random meshes with a random flux-BC pattern (the same for both stress rows);
+    two-cell boundary nodes between flux-BC facets trigger the grouped patches at k = 2."""
+    from dolfinx_eqlb_amd import cpp
+    from dolfinx_eqlb_amd.synthetic import make_compatible_stress_data
+    from test_oracle_stress import asym_moments
+    mesh, ft1, _, _ = random_case(100 + seed, k, 1)
+    ft = np.repeat(ft1, 2, axis=0)
+    G, f = make_compatible_stress_data(mesh, k, ft)
+    try:
+        ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f, stress=True)
+    except RuntimeError as e:  # the reference refuses such meshes too (se/reconstruction.hpp:195-197)
+        pytest.skip(str(e))
+    eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(mesh), k, 2, reconstruct_stress=True)
+    try:
+        eq.set_boundary(ft)
+    except RuntimeError as e:
+        if "overlapping groups" in str(e) or "Incompatible mesh" in str(e):
+            pytest.skip(str(e))
+        raise
+    x = eq.equilibrate_host(G, f)
+    assert np.abs(x - ref).max() <= 1e-9 * np.abs(ref).max()
+    assert np.abs(asym_moments(mesh, k, x)[1]).max() < 1e-9
