@@ -1,11 +1,12 @@
 /*
  * eqlb.h - C ABI of the MI355X-native patch-local flux equilibrator (libeqlb_amd.so).
  *
- * Drop-in boundary for the semi-explicit equilibration hot path of dolfinx_eqlb v1.2.0.
+ * Drop-in boundary for the patch-wise equilibration hot path of dolfinx_eqlb v1.2.0.
  * The reference exposes this path through pybind11 on DOLFINx objects
- * (python/dolfinx_eqlb/wrappers.cpp:97-137 `reconstruct_fluxes_semiexplt[_with_kornconst]`,
- * driver cpp/dolfinx_eqlb/se/reconstruction.hpp:337-407); here the same call takes the flat
- * arrays those objects hold.  Every entry point cites the reference interface it replaces.
+ * (python/dolfinx_eqlb/wrappers.cpp:52-137: `local_solver_*`, `reconstruct_fluxes_minimisation`,
+ * `reconstruct_fluxes_semiexplt[_with_kornconst]`; drivers cpp/dolfinx_eqlb/se/reconstruction.hpp:
+ * 337-407, ev/reconstruction.hpp:32-176, base/local_solver.hpp:38-187); here the same calls take the
+ * flat arrays those objects hold.  Every entry point cites the reference interface it replaces.
  * INTEGRATION.md shows the pybind11/DOLFINx-side adapter a maintainer would add.
  *
  * Conventions: all floating point is fp64, indices int32, flags int8/uint8.  Functions return
@@ -93,16 +94,19 @@ void eqlb_mesh_destroy(eqlb_mesh_t* mesh);
  * cached on the device.  reconstruct_stress / korn are the flags of
  * reconstruct_fluxes_semiexplt[_with_kornconst] (wrappers.cpp:97-137).  reconstruct_stress != 0:
  * the first two RHS are the rows of a stress tensor and the weak symmetry condition is imposed
- * patch-wise after the row-wise equilibration (se/solve_patch_weaksym.hpp:59-233); the grouped
- * boundary patches for RT_2 with flux BCs on the stress (se/reconstruction.hpp:170-234) are not
- * in this build.  estimate_korn is accepted for symmetry with the
+ * patch-wise after the row-wise equilibration (se/solve_patch_weaksym.hpp:59-233), including the
+ * grouped boundary patches for RT_2 with flux BCs on the stress (se/reconstruction.hpp:170-234;
+ * groups that overlap are refused with EQLB_ERR_UNSUPPORTED).  k <= 3 (k = 4 without stress, on
+ * patches of up to 8 facets).  estimate_korn is accepted for symmetry with the
  * reference constructor (the estimate itself is requested per call, see below).
  */
 int eqlb_se_create(eqlb_mesh_t* mesh, int32_t k, int32_t degree_dg, int32_t nrhs,
                    int32_t reconstruct_stress, int32_t estimate_korn, eqlb_se_t** handle);
 void eqlb_se_destroy(eqlb_se_t* handle);
 
-/* Integer options: "solver" (EQLB_SOLVER_*), "scatter" (EQLB_SCATTER_*). */
+/* Integer options: "solver" (EQLB_SOLVER_*; default SHUFFLE, LDS_CHOLESKY for k = 4), "scatter"
+ * (EQLB_SCATTER_*; default AUTO), "fused" (1: all patch-size bins of the slot path in one launch,
+ * default), "timing" (1: record HIP events around the kernels, see eqlb_se_last_kernel_ms). */
 int eqlb_se_set_option(eqlb_se_t* handle, const char* key, int32_t value);
 
 /*
@@ -194,7 +198,7 @@ int32_t eqlb_mesh_max_patch_cells(const eqlb_mesh_t* mesh);
 
 /*
  * Constant reference-cell tensors compiled into the library (tools/gen_tables.py), for tests:
- * name in {"S","F","H","D","B"}; returns the number of doubles copied (<= capacity), or a
+ * name in {"S","F","H","D"}; returns the number of doubles copied (<= capacity), or a
  * negative error.
  */
 int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, double* out,
@@ -203,7 +207,8 @@ int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, dou
 /* With option "timing" = 1 every equilibrate call records HIP events on the launch stream around
  * each kernel (ring of the last 64 calls).  Returns the average device time in ms per launch of
  * kernel `which` over the recorded calls: which = b in 0..4: patch kernel of the bin with
- * P = 4 << b lanes per patch; which = 5: slot-reduction kernel.  Synchronises with the events;
+ * P = 4 << b lanes per patch (single-launch paths - tiled and fused - report in slot 0);
+ * which = 5: slot-reduction kernel (0 on the tiled path).  Synchronises with the events;
  * 0 if nothing was recorded.  Setting the option again resets the ring. */
 double eqlb_se_last_kernel_ms(const eqlb_se_t* handle, int32_t which);
 
