@@ -677,7 +677,7 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
 // (the benchmark / pure-Dirichlet case).  Same mathematics, a fraction of the LDS: the Cholesky
 // factor of A (<= 9 x 9) is computed in registers and parked in LDS, the Schur system lives in
 // registers from the start (rows r = sub, sub + P, the layout of the distributed LU), Y_k = L^-1 B_k
-// is formed per stress row in one 9 x 10 buffer and re-formed after the LU instead of being kept.
+// is formed per stress row in one 9 x 10 buffer; every lane keeps its own columns in registers.
 // 184 doubles of LDS per patch instead of 438 -> about three times the resident waves.
 #ifndef EQLB_WS_LEAN_WAVES
 #define EQLB_WS_LEAN_WAVES 2
@@ -936,9 +936,12 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
     r0[DCM] = (sub < npnt) ? Rg[sub] : 0.0;
     r1[DCM] = (sub + P < npnt) ? Rg[sub + P] : 0.0;
   }
+  double ys0[2][DM], ys1[2][DM]; // the lane's columns of Y_0, Y_1 (kept for the back substitution)
+#pragma unroll
   for (int k = 0; k < 2; ++k)
   {
-    double y0[DM], y1[DM];
+    double(&y0)[DM] = ys0[k];
+    double(&y1)[DM] = ys1[k];
     form_Y(k, y0, y1);
     // publish the substituted columns, then C[r][c] -= y_r . y_c for the lane's rows
 #pragma unroll
@@ -1043,10 +1046,11 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
   }
 
   // ---- u_k = -L^-T (Y_k gamma): partial sums over the lane's columns, group sum, back substitution ----
+#pragma unroll
   for (int k = 0; k < 2; ++k)
   {
-    double y0[DM], y1[DM];
-    form_Y(k, y0, y1);
+    const double(&y0)[DM] = ys0[k];
+    const double(&y1)[DM] = ys1[k];
     double g0 = 0.0, g1 = 0.0; // gamma of the lane's columns
 #pragma unroll
     for (int c = 0; c < W::NPM; ++c)
