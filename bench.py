@@ -66,7 +66,7 @@ def main():
     from dolfinx_eqlb_amd import cpp
     from dolfinx_eqlb_amd import distributed as dd
     from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    from dolfinx_eqlb_amd.synthetic import make_compatible_data
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

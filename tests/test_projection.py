@@ -59,7 +59,6 @@ def test_gpu_local_projection_feeds_equilibration(oracle_mod):
     equilibration; checked against the oracle for the same projected data."""
     from dolfinx_eqlb_amd import cpp
     from dolfinx_eqlb_amd.lsolver import local_projection
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
     k = 2
     mesh, ft, _, _ = make_case(5, k)
     dm = cpp.DeviceMesh(mesh)

@@ -1,6 +1,5 @@
 import time, sys
 sys.path.insert(0, "/root/repo")
-import numpy as np
 from dolfinx_eqlb_amd import cpp
 from dolfinx_eqlb_amd import distributed as dd
 part = dd.StripPartition(500, 0, 1)
