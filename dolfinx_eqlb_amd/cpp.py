@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "eqlb_ev_create", "eqlb_ev_destroy", "eqlb_ev_set_option", "eqlb_ev_set_dofmap",
     "eqlb_ev_num_dofs", "eqlb_ev_set_boundary", "eqlb_ev_equilibrate", "eqlb_ev_num_patches",
     "eqlb_ev_last_kernel_ms", "eqlb_se_tiling_info", "eqlb_se_estimate",
-    "eqlb_halo_pack", "eqlb_halo_unpack_add",
+    "eqlb_halo_pack", "eqlb_halo_unpack_add", "eqlb_ev_estimate",
 ]
 
 _lib = None
@@ -328,8 +328,9 @@ def project_dg(dmesh: DeviceMesh, degree: int, qpoints, qweights, qvalues, bs: i
     return out
 
 
-def estimate(dmesh: DeviceMesh, k: int, flux_hdiv, flux_dg, rhs_dg):
-    """eqlb_se_estimate on host arrays [nrhs, ...]: returns (cell_div2 [nrhs, ncells],
+def estimate(dmesh: DeviceMesh, k: int, flux_hdiv, flux_dg, rhs_dg, conforming_flux=False):
+    """eqlb_se_estimate (eqlb_ev_estimate with conforming_flux=True: the flux is an EV result in
+    the broken layout) on host arrays [nrhs, ...]: returns (cell_div2 [nrhs, ncells],
     cell_sig2 [nrhs, ncells], facet_jump [nrhs, nfacets])."""
     m = dmesh.mesh
     nrt, nd = k * (k + 2), k * (k + 1) // 2
@@ -342,8 +343,9 @@ def estimate(dmesh: DeviceMesh, k: int, flux_hdiv, flux_dg, rhs_dg):
     div2 = np.zeros((nrhs, m.ncells))
     sig2 = np.zeros((nrhs, m.ncells))
     jump = np.zeros((nrhs, m.nfacets))
-    _check(lib().eqlb_se_estimate(dmesh._h, C.c_int32(k), C.c_int32(nrhs), _hp(x), _hp(g), _hp(f),
-                                  _hp(div2), _hp(sig2), _hp(jump), C.c_int32(MEM_HOST), None))
+    fn = lib().eqlb_ev_estimate if conforming_flux else lib().eqlb_se_estimate
+    _check(fn(dmesh._h, C.c_int32(k), C.c_int32(nrhs), _hp(x), _hp(g), _hp(f),
+              _hp(div2), _hp(sig2), _hp(jump), C.c_int32(MEM_HOST), None))
     return div2, sig2, jump
 
 

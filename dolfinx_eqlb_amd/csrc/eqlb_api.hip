@@ -1121,9 +1121,10 @@ int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, dou
   return (int)len;
 }
 
-int eqlb_se_estimate(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const double* flux_hdiv,
-                     const double* flux_dg, const double* rhs_dg, double* cell_div2,
-                     double* cell_sig2, double* facet_jump, int32_t memspace, void* stream_)
+static int estimate_impl(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const double* flux_hdiv,
+                         const double* flux_dg, const double* rhs_dg, double* cell_div2,
+                         double* cell_sig2, double* facet_jump, int32_t memspace, void* stream_,
+                         double alpha, double beta)
 {
   if (!mesh || !flux_hdiv || !flux_dg || !rhs_dg || nrhs < 1 || k < 1 || k > 3)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_estimate: invalid argument");
@@ -1136,7 +1137,7 @@ int eqlb_se_estimate(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const double* f
   if (memspace == EQLB_MEM_DEVICE)
   {
     const int st = eqlb::launch_estimate(m, k, nrhs, flux_hdiv, flux_dg, rhs_dg, cell_div2, cell_sig2,
-                                         facet_jump, stream);
+                                         facet_jump, alpha, beta, stream);
     return st ? fail(st, "eqlb_se_estimate: kernel launch failed") : EQLB_OK;
   }
   if (memspace != EQLB_MEM_HOST)
@@ -1149,7 +1150,7 @@ int eqlb_se_estimate(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const double* f
     st |= upload<double>(&d_s, nullptr, n_c);
   if (facet_jump)
     st |= upload<double>(&d_j, nullptr, n_e);
-  int rc = st ? EQLB_ERR_DEVICE : eqlb::launch_estimate(m, k, nrhs, d_x, d_g, d_f, d_d, d_s, d_j, stream);
+  int rc = st ? EQLB_ERR_DEVICE : eqlb::launch_estimate(m, k, nrhs, d_x, d_g, d_f, d_d, d_s, d_j, alpha, beta, stream);
   hipError_t e = hipSuccess;
   if (!rc && cell_div2)
     e = hipMemcpy(cell_div2, d_d, n_c * sizeof(double), hipMemcpyDeviceToHost);
@@ -1166,6 +1167,22 @@ int eqlb_se_estimate(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const double* f
   if (rc || e != hipSuccess)
     return fail(EQLB_ERR_DEVICE, "eqlb_se_estimate: device error");
   return EQLB_OK;
+}
+
+int eqlb_se_estimate(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const double* flux_hdiv,
+                     const double* flux_dg, const double* rhs_dg, double* cell_div2,
+                     double* cell_sig2, double* facet_jump, int32_t memspace, void* stream)
+{
+  return estimate_impl(mesh, k, nrhs, flux_hdiv, flux_dg, rhs_dg, cell_div2, cell_sig2, facet_jump,
+                       memspace, stream, 0.0, 1.0);
+}
+
+int eqlb_ev_estimate(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const double* flux_broken,
+                     const double* flux_dg, const double* rhs_dg, double* cell_div2,
+                     double* cell_sig2, double* facet_jump, int32_t memspace, void* stream)
+{
+  return estimate_impl(mesh, k, nrhs, flux_broken, flux_dg, rhs_dg, cell_div2, cell_sig2, facet_jump,
+                       memspace, stream, -1.0, 0.0);
 }
 
 int eqlb_halo_pack(int32_t nrhs, int32_t nlist, int32_t nrt, int64_t ncells, const int64_t* cells,

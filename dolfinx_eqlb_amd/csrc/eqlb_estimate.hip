@@ -1,8 +1,9 @@
 // Acceptance predicates and estimator quantities on the device - the step right after the
 // equilibration in the reference's workflows: the divergence / jump checks of
 // python/dolfinx_eqlb/eqlb/check_eqlb_conditions.py:183-359 and the cell-wise flux indicator
-// || sigma_eq ||^2_T of demo/poisson/demo_error_estimation.py:52-124 (err_sig for the discontinuous
-// SE flux).  Quadrature-free like the patch kernel: with rho = detJ * (Pi f - div(sigma_eq + G)) in
+// of demo/poisson/demo_error_estimation.py:52-124: || sigma_eq ||^2_T for the discontinuous SE flux
+// (alpha = 0, beta = 1: the total flux is sigma_eq + G), || sigma_eq - G ||^2_T for a conforming (EV)
+// flux given in the broken layout (alpha = -1, beta = 0: the total flux is sigma_eq itself).  Quadrature-free like the patch kernel: with rho = detJ * (Pi f - div(sigma_eq + G)) in
 // P_{k-1}(ref) and m_q = int rho mono_q,
 //   || Pi f - div(sigma_eq + G) ||^2_T = m^T GMI m / |detJ|,   || sigma_eq ||^2_T = c^T (sum_x g_x S_x) c,
 // and the normal-flux jump of sigma_eq + G on an interior facet from the outward moments of both
@@ -21,7 +22,8 @@ struct EstTables
   static constexpr int NRT = R::NRT, ND = R::ND, NQ = R::NQ;
   static constexpr int OFF_S = 0, OFF_HG = OFF_S + R::S_SIZE, OFF_DM = OFF_HG + R::HG_SIZE,
                        OFF_GMI = OFF_DM + R::DM_SIZE, OFF_F0 = OFF_GMI + R::GMI_SIZE,
-                       TOTAL = OFF_F0 + R::F0_SIZE;
+                       OFF_MRD = OFF_F0 + R::F0_SIZE, OFF_MPS = OFF_MRD + R::MRD_SIZE,
+                       TOTAL = OFF_MPS + R::MPS_SIZE;
   static void fill(std::vector<double>& t)
   {
     t.clear();
@@ -30,6 +32,8 @@ struct EstTables
     t.insert(t.end(), R::DM, R::DM + R::DM_SIZE);
     t.insert(t.end(), R::GMI, R::GMI + R::GMI_SIZE);
     t.insert(t.end(), R::F0, R::F0 + R::F0_SIZE);
+    t.insert(t.end(), R::MRD, R::MRD + R::MRD_SIZE);
+    t.insert(t.end(), R::MPS, R::MPS + R::MPS_SIZE);
   }
 };
 
@@ -38,7 +42,8 @@ template <int K>
 __global__ void __launch_bounds__(256)
 k_estimate_cells(int32_t ncells, const double* __restrict__ tab, const double* __restrict__ cellJ,
                  const double* __restrict__ x_eq, const double* __restrict__ flux_dg,
-                 const double* __restrict__ rhs_dg, double* __restrict__ div2, double* __restrict__ sig2)
+                 const double* __restrict__ rhs_dg, double* __restrict__ div2, double* __restrict__ sig2,
+                 const double alpha, const double beta)
 {
   using E = EstTables<K>;
   constexpr int NRT = E::NRT, ND = E::ND, NQ = E::NQ;
@@ -73,7 +78,7 @@ k_estimate_cells(int32_t ncells, const double* __restrict__ tab, const double* _
     for (int i = 0; i < ND; ++i)
     {
       const double gx = G[2 * i], gy = G[2 * i + 1];
-      const double h0 = a00 * gx + a01 * gy, h1 = a10 * gx + a11 * gy, fd = detJ * f[i];
+      const double h0 = beta * (a00 * gx + a01 * gy), h1 = beta * (a10 * gx + a11 * gy), fd = detJ * f[i];
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
         m[q] += fd * st[E::OFF_HG + i * NQ + q] - h0 * st[E::OFF_DM + (i * 2 + 0) * NQ + q]
@@ -107,6 +112,25 @@ k_estimate_cells(int32_t ncells, const double* __restrict__ tab, const double* _
       s += cf[i] * r;
     }
     // S1 holds phi_i^x phi_j^y + phi_i^y phi_j^x, so c^T S1 c counts the mixed term twice as needed
+    if (alpha != 0.0)
+    {
+      // || sigma + alpha G ||^2 = || sigma ||^2 + 2 alpha (sigma, G) + alpha^2 (G, G)
+      const double sg = (detJ > 0.0) ? 1.0 : -1.0;
+      const double* G = flux_dg + (int64_t)c * ND * 2;
+      double sgm = 0.0, gg = 0.0;
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+      {
+        const double gx = G[2 * d], gy = G[2 * d + 1];
+        const double t0 = J00 * gx + J10 * gy, t1 = J01 * gx + J11 * gy; // J^T G_d
+        for (int i = 0; i < NRT; ++i)
+          sgm += cf[i] * (st[E::OFF_MRD + (i * ND + d) * 2] * t0 + st[E::OFF_MRD + (i * ND + d) * 2 + 1] * t1);
+#pragma unroll
+        for (int e = 0; e < ND; ++e)
+          gg += st[E::OFF_MPS + d * ND + e] * (gx * G[2 * e] + gy * G[2 * e + 1]);
+      }
+      s += 2.0 * alpha * sg * sgm + alpha * alpha * fabs(detJ) * gg;
+    }
     sig2[c] = s;
   }
 }
@@ -114,7 +138,8 @@ k_estimate_cells(int32_t ncells, const double* __restrict__ tab, const double* _
 // outward moments of (sigma_eq + G) on local facet lf of cell c
 template <int K>
 __device__ __forceinline__ void facet_moments(const double* st, const double* cellJ, const double* x_eq,
-                                              const double* flux_dg, int32_t c, int lf, double* mu)
+                                              const double* flux_dg, int32_t c, int lf, double beta,
+                                              double* mu)
 {
   using E = EstTables<K>;
   constexpr int NRT = E::NRT, ND = E::ND;
@@ -131,7 +156,7 @@ __device__ __forceinline__ void facet_moments(const double* st, const double* ce
 #pragma unroll
   for (int i = 0; i < ND; ++i)
   {
-    const double gn = G[2 * i] * nu0 + G[2 * i + 1] * nu1;
+    const double gn = beta * (G[2 * i] * nu0 + G[2 * i + 1] * nu1);
 #pragma unroll
     for (int j = 0; j < K; ++j)
       mu[j] += st[E::OFF_F0 + (lf * ND + i) * K + j] * gn;
@@ -148,7 +173,7 @@ k_estimate_facets(int32_t nfacets, const double* __restrict__ tab, const double*
                   const int32_t* __restrict__ cell_facets, const uint8_t* __restrict__ facet_perm,
                   const int32_t* __restrict__ facet_cells_off, const int32_t* __restrict__ facet_cells,
                   const double* __restrict__ x_eq, const double* __restrict__ flux_dg,
-                  double* __restrict__ jump)
+                  double* __restrict__ jump, const double beta)
 {
   using E = EstTables<K>;
   extern __shared__ double st[];
@@ -175,8 +200,8 @@ k_estimate_facets(int32_t nfacets, const double* __restrict__ tab, const double*
       l1 = l;
   }
   double m0[K], m1[K];
-  facet_moments<K>(st, cellJ, x_eq, flux_dg, c0, l0, m0);
-  facet_moments<K>(st, cellJ, x_eq, flux_dg, c1, l1, m1);
+  facet_moments<K>(st, cellJ, x_eq, flux_dg, c0, l0, beta, m0);
+  facet_moments<K>(st, cellJ, x_eq, flux_dg, c1, l1, beta, m1);
   const bool rev = facet_perm[(int64_t)c0 * 3 + l0] != facet_perm[(int64_t)c1 * 3 + l1];
   double worst = 0.0;
 #pragma unroll
@@ -193,8 +218,8 @@ k_estimate_facets(int32_t nfacets, const double* __restrict__ tab, const double*
 
 template <int K>
 static int launch_estimate_k(const DeviceMesh& m, int nrhs, const double* x_eq, const double* flux_dg,
-                             const double* rhs_dg, double* div2, double* sig2, double* jump,
-                             hipStream_t stream)
+                             const double* rhs_dg, double* div2, double* sig2, double* jump, double alpha,
+                             double beta, hipStream_t stream)
 {
   using E = EstTables<K>;
   std::vector<double> t;
@@ -211,11 +236,11 @@ static int launch_estimate_k(const DeviceMesh& m, int nrhs, const double* x_eq, 
       hipLaunchKernelGGL(k_estimate_cells<K>, dim3((m.ncells + 255) / 256), dim3(256), lds, stream, m.ncells,
                          d_t, m.cellJ, x_eq + r * nx, flux_dg + r * ng, rhs_dg + r * nf,
                          div2 ? div2 + (int64_t)r * m.ncells : nullptr,
-                         sig2 ? sig2 + (int64_t)r * m.ncells : nullptr);
+                         sig2 ? sig2 + (int64_t)r * m.ncells : nullptr, alpha, beta);
     if (jump)
       hipLaunchKernelGGL(k_estimate_facets<K>, dim3((m.nfacets + 255) / 256), dim3(256), lds, stream,
                          m.nfacets, d_t, m.cellJ, m.cell_facets, m.facet_perm, m.facet_cells_off,
-                         m.facet_cells, x_eq + r * nx, flux_dg + r * ng, jump + (int64_t)r * m.nfacets);
+                         m.facet_cells, x_eq + r * nx, flux_dg + r * ng, jump + (int64_t)r * m.nfacets, beta);
     e = hipGetLastError();
   }
   if (e == hipSuccess)
@@ -225,14 +250,15 @@ static int launch_estimate_k(const DeviceMesh& m, int nrhs, const double* x_eq, 
 }
 
 int launch_estimate(const DeviceMesh& m, int k, int nrhs, const double* x_eq, const double* flux_dg,
-                    const double* rhs_dg, double* div2, double* sig2, double* jump, hipStream_t stream)
+                    const double* rhs_dg, double* div2, double* sig2, double* jump, double alpha,
+                    double beta, hipStream_t stream)
 {
   if (k == 1)
-    return launch_estimate_k<1>(m, nrhs, x_eq, flux_dg, rhs_dg, div2, sig2, jump, stream);
+    return launch_estimate_k<1>(m, nrhs, x_eq, flux_dg, rhs_dg, div2, sig2, jump, alpha, beta, stream);
   if (k == 2)
-    return launch_estimate_k<2>(m, nrhs, x_eq, flux_dg, rhs_dg, div2, sig2, jump, stream);
+    return launch_estimate_k<2>(m, nrhs, x_eq, flux_dg, rhs_dg, div2, sig2, jump, alpha, beta, stream);
   if (k == 3)
-    return launch_estimate_k<3>(m, nrhs, x_eq, flux_dg, rhs_dg, div2, sig2, jump, stream);
+    return launch_estimate_k<3>(m, nrhs, x_eq, flux_dg, rhs_dg, div2, sig2, jump, alpha, beta, stream);
   return EQLB_ERR_UNSUPPORTED;
 }
 

@@ -172,7 +172,8 @@ void launch_korn(const DeviceMesh& m, const int64_t* node_slot, const int64_t* n
                  const int32_t* slot_cell, const uint32_t* slot_info, const uint8_t* pn,
                  const uint8_t* pflag, double* cks, double* korn, hipStream_t stream);
 int launch_estimate(const DeviceMesh& m, int k, int nrhs, const double* x_eq, const double* flux_dg,
-                    const double* rhs_dg, double* div2, double* sig2, double* jump, hipStream_t stream);
+                    const double* rhs_dg, double* div2, double* sig2, double* jump, double alpha,
+                    double beta, hipStream_t stream);
 void launch_halo_pack(int nrhs, int32_t nlist, int32_t nrt, int64_t ncells, const int64_t* cells, double* x,
                       double* buf, int clear, hipStream_t stream);
 void launch_halo_unpack_add(int nrhs, int32_t nlist, int32_t nrt, int64_t ncells, const int64_t* cells,

@@ -225,6 +225,14 @@ int eqlb_se_estimate(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const double* f
                      const double* flux_dg, const double* rhs_dg, double* cell_div2,
                      double* cell_sig2, double* facet_jump, int32_t memspace, void* stream);
 
+/* The same quantities for a conforming (EV) flux handed over in the broken layout
+ * (eqlb_ev_set_option "output" = 1): the total flux is sigma_eq itself, so
+ *   cell_div2 = || Pi f - div sigma_eq ||^2_T,  cell_sig2 = || sigma_eq - G ||^2_T  (err_sig =
+ *   grad(u_h) + sigma_eqlb of demo_error_estimation.py:97-100),  facet_jump = jump moments of sigma_eq. */
+int eqlb_ev_estimate(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const double* flux_broken,
+                     const double* flux_dg, const double* rhs_dg, double* cell_div2,
+                     double* cell_sig2, double* facet_jump, int32_t memspace, void* stream);
+
 /* Multi-GPU decomposition by node ownership (the reference has no distributed
  * equilibration, se/reconstruction.hpp:90 loops the owned nodes only): after the local sweep the
  * partial sums of the ghost-cell rows are sent to the owning rank and added there.  DEVICE pointers:

@@ -128,3 +128,25 @@ def test_ev_guaranteed_upper_bound(oracle_mod, k):
     eta_se = estimate(flux_norm2(mesh, k, xs), osc2, h)
     assert 1.0 - 1e-10 <= eta_ev / err < 2.0
     assert eta_ev < 1.5 * eta_se
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_gpu_ev_pipeline_bound(k):
+    """EV on the device: equilibrate (broken output) -> eqlb_ev_estimate; guaranteed bound."""
+    from dolfinx_eqlb_amd import cpp
+    mesh, ft, G, fh, osc2, h, err = problem(10, k)
+    dm = cpp.DeviceMesh(mesh)
+    ev = cpp.ConstrainedMinEquilibrator(dm, k, 1)
+    ev.set_option("output", 1)
+    ev.set_boundary(ft)
+    xb = ev.equilibrate_host(G[None], fh[None])
+    div2, sig2, jump = cpp.estimate(dm, k, xb, G[None], fh[None], conforming_flux=True)
+    assert np.sqrt(div2.sum()) < 1e-9 * np.sqrt(np.sum(fh ** 2)) and jump.max() < 1e-9
+    ref = ev_flux_error2(mesh, k, xb[0], G)
+    # || sigma - G ||^2 is evaluated as (sigma, sigma) - 2 (sigma, G) + (G, G): the difference of
+    # O(|G|^2 |T|) terms, so the tolerance is relative to that scale
+    scale = np.abs(G).max() ** 2 * np.abs(chk.cell_geometry(mesh)[1]).max()
+    assert np.allclose(sig2[0], ref, rtol=1e-6, atol=1e-13 * scale)
+    eta = estimate(sig2[0], osc2, h)
+    assert 1.0 - 1e-10 <= eta / err < 2.2

@@ -125,8 +125,13 @@ def tables_exact(k, deg):
     GMI = P.solve_exact(gram, [[Fraction(int(a == b)) for b in range(nq_)] for a in range(nq_)])
     F0 = [[[sum(F[f][n][i][j] for n in range(3)) for j in range(k)] for i in range(nd)]
           for f in range(3)]
+    # flux part of the estimator for a flux sigma given next to the discrete flux G (EV):
+    # MRD[i][d][c] = int phi_i^c psi_d, MPS[d][e] = int psi_d psi_e
+    MRD = [[[P.integrate_triangle(P.mul(rt.basis[i][c], dg.basis[d])) for c in range(2)]
+            for d in range(nd)] for i in range(nrt)]
+    MPS = [[P.integrate_triangle(P.mul(dg.basis[d], dg.basis[e])) for e in range(nd)] for d in range(nd)]
     return dict(k=k, deg=deg, nrt=nrt, nd=nd, nq=len(monos), S=S, F=F, H=H, D=D, B=B, TE=TE, WQ=WQ,
-                V=V, VQ=VQ, HB=HB, HG=HG, WGF=WGF, WG=WG, DM=DM, GMI=GMI, F0=F0)
+                V=V, VQ=VQ, HB=HB, HG=HG, WGF=WGF, WG=WG, DM=DM, GMI=GMI, F0=F0, MRD=MRD, MPS=MPS)
 
 
 def _local_maps(k, B, fm, fp, rev):
@@ -245,7 +250,7 @@ def tables_float(k, deg):
     t = tables_exact(k, deg)
     out = dict(k=k, deg=deg, nrt=t["nrt"], nd=t["nd"], nq=t["nq"])
     for name in ("S", "F", "H", "D", "B", "TE", "WQ", "V", "VQ", "HB", "HG", "WGF", "WG", "DM", "GMI",
-                 "F0"):
+                 "F0", "MRD", "MPS"):
         def shape(x):
             return (len(x),) + shape(x[0]) if isinstance(x, list) else ()
         out[name] = np.array([float(v) for v in _flat(t[name])]).reshape(shape(t[name]))
@@ -291,6 +296,8 @@ def emit(path):
         arr("DM", (nd, 2, nq), t["DM"])
         arr("GMI", (nq, nq), t["GMI"])
         arr("F0", (3, nd, k), t["F0"])
+        arr("MRD", (nrt, nd, 2), t["MRD"])
+        arr("MPS", (nd, nd), t["MPS"])
         lines.append("};")
         lines.append("")
     # Lagrange P_d (Basix numbering, equispaced): monomial coefficients and inverse mass matrix
