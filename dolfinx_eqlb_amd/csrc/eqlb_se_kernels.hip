@@ -680,8 +680,12 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         {
           Lv[h] -= T[h][NC] * la;
 #pragma unroll
-          for (int g = 0; g < NC; ++g)
-            T[h][g] -= ca[h] * T[NC][g];
+          for (int g = 0; g <= h; ++g) // symmetric update: one triangle, mirrored
+          {
+            const double v = T[h][g] - ca[h] * T[NC][g];
+            T[h][g] = v;
+            T[g][h] = v;
+          }
         }
       }
       // (c) block row of facet E_sub: own minus-side blocks + plus-side blocks of the previous cell
