@@ -975,6 +975,11 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
 
   // ---- distributed LU with partial pivoting (as in k_se_weaksym) ----
   double gam[DCM];
+#ifdef EQLB_WSL_SKIP_LU // timing experiment (wrong results)
+#pragma unroll
+  for (int c = 0; c < DCM; ++c)
+    gam[c] = r0[c] + r1[c];
+#else
   {
     bool free0 = sub < dim_c, free1 = sub + P < dim_c;
     int prow[DCM];
@@ -1044,6 +1049,7 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
       }
     }
   }
+#endif
 
   // ---- u_k = -L^-T (Y_k gamma): partial sums over the lane's columns, group sum, back substitution ----
 #pragma unroll
