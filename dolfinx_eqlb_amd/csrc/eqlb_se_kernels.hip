@@ -74,6 +74,10 @@ int fill_tables_host(int k, int deg, std::vector<double>& out)
   return (out.size() == table_doubles(k, deg)) ? 0 : EQLB_ERR_UNSUPPORTED;
 }
 
+#ifndef EQLB_CHAIN_PCR
+#define EQLB_CHAIN_PCR 1 // RT_2 chain solve by parallel cyclic reduction (0: sequential elimination)
+#endif
+
 // ---- the patch kernel ---------------------------------------------------------------------------
 // MODE 0: semi-explicit equilibration.  MODE 1: the constrained-minimisation patch problem of
 // ev/solve_patch.hpp:58-238 (mixed RT_k x DG_{k-1} saddle point, (ndof+1)^2 LU per patch in the
@@ -764,201 +768,292 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
           Rp[aa][2 + bb] = c0;
         }
       }
-      // small SPD inverse (KB = 1, 2), X = Einv Rp, Y = Einv OffC
-      double Ei[KB][KB], X[KB][1 + W], Y[KB][KB];
-      auto finish_row = [&]() {
-        if constexpr (KB == 1)
-          Ei[0][0] = rcp_d(Dp[0][0]);
-        else
-        {
-          const double det = Dp[0][0] * Dp[1][1] - Dp[0][1] * Dp[1][0];
-          const double id = rcp_d(det);
-          Ei[0][0] = Dp[1][1] * id;
-          Ei[1][1] = Dp[0][0] * id;
-          Ei[0][1] = -Dp[0][1] * id;
-          Ei[1][0] = -Dp[1][0] * id;
-        }
-#pragma unroll
-        for (int aa = 0; aa < KB; ++aa)
-        {
-#pragma unroll
-          for (int c = 0; c < 1 + W; ++c)
-          {
-            double v = 0.0;
-#pragma unroll
-            for (int e = 0; e < KB; ++e)
-              v += Ei[aa][e] * Rp[e][c];
-            X[aa][c] = v;
-          }
-#pragma unroll
-          for (int bb = 0; bb < KB; ++bb)
-          {
-            double v = 0.0;
-#pragma unroll
-            for (int e = 0; e < KB; ++e)
-              v += Ei[aa][e] * OffC[e][bb];
-            Y[aa][bb] = v;
-          }
-        }
-      };
-      // (e) forward elimination down the chain: lane s receives OffC^T Einv [OffC | Rp] of lane s-1
-#pragma unroll 1
-      for (int s = 2; s < P; ++s)
+      double zz[W], xs[KB];
+      if constexpr (KB == 1 && P <= 16 && EQLB_CHAIN_PCR)
       {
-        finish_row();
-        double P1[KB][KB], P2[KB][1 + W];
-#pragma unroll
-        for (int aa = 0; aa < KB; ++aa)
+        // (e') RT_2: the chain is a scalar symmetric tridiagonal system with three right-hand sides
+        // [rr | column of d | column of x_0].  Parallel cyclic reduction: log2(P) levels in which
+        // EVERY lane eliminates its couplings to the rows i - s and i + s (DPP row shifts), instead
+        // of P - 2 sequential hand-offs down the chain and P - 2 back up.  a = coupling to row
+        // i - s (the coupling to i + s is a of lane i + s: the level matrices stay symmetric);
+        // rows outside the chain are identity rows, couplings across the ends are exact zeros, so
+        // what a shift drags in from a neighbouring patch group is multiplied by zero.
+        double b = Dp[0][0], r0 = Rp[0][0], r1 = Rp[0][1], r2 = Rp[0][2];
+        const double B1 = Rp[0][1], B2 = Rp[0][2];
+        double am = dpp_d<0x111>(OffC[0][0]);
+        if (sub == 0)
+          am = 0.0;
+#define EQLB_PCR_LEVEL(S)                                                                          \
+  if constexpr (P > S)                                                                             \
+  {                                                                                                \
+    if (!(b > 0.0))                                                                                \
+    {                                                                                              \
+      status_local = pvalid ? 1 : status_local;                                                    \
+      b = 1.0;                                                                                     \
+    }                                                                                              \
+    const double ib = rcp_d(b);                                                                    \
+    const double ib_lo = dpp_d<0x110 + S>(ib), a_lo = dpp_d<0x110 + S>(am);                        \
+    const double r0_lo = dpp_d<0x110 + S>(r0), r1_lo = dpp_d<0x110 + S>(r1), r2_lo = dpp_d<0x110 + S>(r2); \
+    const double ib_hi = dpp_d<0x100 + S>(ib), a_hi = dpp_d<0x100 + S>(am);                        \
+    const double r0_hi = dpp_d<0x100 + S>(r0), r1_hi = dpp_d<0x100 + S>(r1), r2_hi = dpp_d<0x100 + S>(r2); \
+    const double cp = (sub + S < P) ? a_hi : 0.0; /* coupling to row i + S */                      \
+    const double al = am * ib_lo, ga = cp * ib_hi;                                                 \
+    b = __builtin_fma(-ga, cp, __builtin_fma(-al, am, b));                                         \
+    r0 = __builtin_fma(-ga, r0_hi, __builtin_fma(-al, r0_lo, r0));                                 \
+    r1 = __builtin_fma(-ga, r1_hi, __builtin_fma(-al, r1_lo, r1));                                 \
+    r2 = __builtin_fma(-ga, r2_hi, __builtin_fma(-al, r2_lo, r2));                                 \
+    am = (sub >= 2 * S) ? -al * a_lo : 0.0;                                                        \
+  }
+        EQLB_PCR_LEVEL(1)
+        EQLB_PCR_LEVEL(2)
+        EQLB_PCR_LEVEL(4)
+        EQLB_PCR_LEVEL(8)
+#undef EQLB_PCR_LEVEL
+        if (!(b > 0.0))
         {
-#pragma unroll
-          for (int bb = 0; bb < KB; ++bb)
-          {
-            double v = 0.0;
-#pragma unroll
-            for (int e = 0; e < KB; ++e)
-              v += OffC[e][aa] * Y[e][bb];
-            P1[aa][bb] = v;
-          }
-#pragma unroll
-          for (int c = 0; c < 1 + W; ++c)
-          {
-            double v = 0.0;
-#pragma unroll
-            for (int e = 0; e < KB; ++e)
-              v += OffC[e][aa] * X[e][c];
-            P2[aa][c] = v;
-          }
+          status_local = pvalid ? 1 : status_local;
+          b = 1.0;
         }
-        const bool take = in_chain && sub == s;
-#pragma unroll
-        for (int aa = 0; aa < KB; ++aa)
+        const double ibf = rcp_d(b);
+        const double s0 = r0 * ibf, s1 = r1 * ibf, s2 = r2 * ibf; // A^-1 [rr | bt | c0]
+        // (f') Schur complement of the chain on the border [d ; x_0]
+        double tred[W], Sred[W][W];
+        tred[0] = group_sum_d<P>(B1 * s0, gbase, sub);
+        tred[1] = group_sum_d<P>(B2 * s0, gbase, sub);
+        Sred[0][0] = group_sum_d<P>(B1 * s1, gbase, sub);
+        Sred[1][0] = group_sum_d<P>(B2 * s1, gbase, sub);
+        Sred[1][1] = group_sum_d<P>(B2 * s2, gbase, sub);
         {
-#pragma unroll
-          for (int bb = 0; bb < KB; ++bb)
-          {
-            const double v = lane_down_d<P, 1>(P1[aa][bb], gbase, sub);
-            if (take)
-              Dp[aa][bb] -= v;
-          }
-#pragma unroll
-          for (int c = 0; c < 1 + W; ++c)
-          {
-            const double v = lane_down_d<P, 1>(P2[aa][c], gbase, sub);
-            if (take)
-              Rp[aa][c] -= v;
-          }
-        }
-      }
-      finish_row();
-      // (f) Schur complement of the chain on the border, W x W solve
-      double Sred[W][W], tred[W];
-#pragma unroll
-      for (int c = 0; c < W; ++c)
-      {
-        double v = 0.0;
-#pragma unroll
-        for (int e = 0; e < KB; ++e)
-          v += Rp[e][1 + c] * X[e][0];
-        tred[c] = v;
-#pragma unroll
-        for (int c2 = 0; c2 <= c; ++c2)
-        {
-          double u2 = 0.0;
-#pragma unroll
-          for (int e = 0; e < KB; ++e)
-            u2 += Rp[e][1 + c] * X[e][1 + c2];
-          Sred[c][c2] = u2;
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < W; ++c)
-      {
-        tred[c] = group_sum_d<P>(tred[c], gbase, sub);
-#pragma unroll
-        for (int c2 = 0; c2 <= c; ++c2)
-          Sred[c][c2] = group_sum_d<P>(Sred[c][c2], gbase, sub);
-      }
-      double zz[W];
-      {
-        // Cholesky of Z - S (lower), then two triangular solves
-        double Lz[W][W], iLz[W];
-#pragma unroll
-        for (int c = 0; c < W; ++c)
-        {
-          rz[c] -= tred[c];
-#pragma unroll
-          for (int c2 = 0; c2 <= c; ++c2)
-            Lz[c][c2] = Z[c][c2] - Sred[c][c2];
-        }
-#pragma unroll
-        for (int j = 0; j < W; ++j)
-        {
-          double dj = Lz[j][j];
-#pragma unroll
-          for (int q = 0; q < j; ++q)
-            dj -= Lz[j][q] * Lz[j][q];
-          if (!(dj > 0.0))
+          const double l00 = Z[0][0] - Sred[0][0], l10 = Z[1][0] - Sred[1][0];
+          double d1 = Z[1][1] - Sred[1][1];
+          double d0 = l00;
+          if (!(d0 > 0.0))
           {
             status_local = pvalid ? 1 : status_local;
-            dj = 1.0;
+            d0 = 1.0;
           }
-          const double ilj = rsqrt_d(dj), lj = dj * ilj;
-          Lz[j][j] = lj;
-          iLz[j] = ilj;
-#pragma unroll
-          for (int i = j + 1; i < W; ++i)
+          const double i0 = rcp_d(d0);
+          const double m = l10 * i0;
+          d1 = __builtin_fma(-m, l10, d1);
+          if (!(d1 > 0.0))
           {
-            double v = Lz[i][j];
-#pragma unroll
-            for (int q = 0; q < j; ++q)
-              v -= Lz[i][q] * Lz[j][q];
-            Lz[i][j] = v * ilj;
+            status_local = pvalid ? 1 : status_local;
+            d1 = 1.0;
+          }
+          const double q0 = rz[0] - tred[0];
+          const double q1 = __builtin_fma(-m, q0, rz[1] - tred[1]);
+          zz[1] = q1 * rcp_d(d1);
+          zz[0] = __builtin_fma(-l10, zz[1], q0) * i0;
+        }
+        const double v = __builtin_fma(-s2, zz[1], __builtin_fma(-s1, zz[0], s0));
+        xs[0] = in_chain ? v : 0.0;
+      }
+      else
+      {
+        // small SPD inverse (KB = 1, 2), X = Einv Rp, Y = Einv OffC
+        double Ei[KB][KB], X[KB][1 + W], Y[KB][KB];
+        auto finish_row = [&]() {
+          if constexpr (KB == 1)
+            Ei[0][0] = rcp_d(Dp[0][0]);
+          else
+          {
+            const double det = Dp[0][0] * Dp[1][1] - Dp[0][1] * Dp[1][0];
+            const double id = rcp_d(det);
+            Ei[0][0] = Dp[1][1] * id;
+            Ei[1][1] = Dp[0][0] * id;
+            Ei[0][1] = -Dp[0][1] * id;
+            Ei[1][0] = -Dp[1][0] * id;
+          }
+  #pragma unroll
+          for (int aa = 0; aa < KB; ++aa)
+          {
+  #pragma unroll
+            for (int c = 0; c < 1 + W; ++c)
+            {
+              double v = 0.0;
+  #pragma unroll
+              for (int e = 0; e < KB; ++e)
+                v += Ei[aa][e] * Rp[e][c];
+              X[aa][c] = v;
+            }
+  #pragma unroll
+            for (int bb = 0; bb < KB; ++bb)
+            {
+              double v = 0.0;
+  #pragma unroll
+              for (int e = 0; e < KB; ++e)
+                v += Ei[aa][e] * OffC[e][bb];
+              Y[aa][bb] = v;
+            }
+          }
+        };
+        // (e) forward elimination down the chain: lane s receives OffC^T Einv [OffC | Rp] of lane s-1
+  #ifdef EQLB_EXP_CHAIN3 // timing experiment (wrong results): log2(P) elimination steps, no back substitution
+        constexpr int SEND = (P == 8) ? 5 : ((P == 16) ? 6 : P);
+  #else
+        constexpr int SEND = P;
+  #endif
+  #pragma unroll 1
+        for (int s = 2; s < SEND; ++s)
+        {
+          finish_row();
+          double P1[KB][KB], P2[KB][1 + W];
+  #pragma unroll
+          for (int aa = 0; aa < KB; ++aa)
+          {
+  #pragma unroll
+            for (int bb = 0; bb < KB; ++bb)
+            {
+              double v = 0.0;
+  #pragma unroll
+              for (int e = 0; e < KB; ++e)
+                v += OffC[e][aa] * Y[e][bb];
+              P1[aa][bb] = v;
+            }
+  #pragma unroll
+            for (int c = 0; c < 1 + W; ++c)
+            {
+              double v = 0.0;
+  #pragma unroll
+              for (int e = 0; e < KB; ++e)
+                v += OffC[e][aa] * X[e][c];
+              P2[aa][c] = v;
+            }
+          }
+          const bool take = in_chain && sub == s;
+  #pragma unroll
+          for (int aa = 0; aa < KB; ++aa)
+          {
+  #pragma unroll
+            for (int bb = 0; bb < KB; ++bb)
+            {
+              const double v = lane_down_d<P, 1>(P1[aa][bb], gbase, sub);
+              if (take)
+                Dp[aa][bb] -= v;
+            }
+  #pragma unroll
+            for (int c = 0; c < 1 + W; ++c)
+            {
+              const double v = lane_down_d<P, 1>(P2[aa][c], gbase, sub);
+              if (take)
+                Rp[aa][c] -= v;
+            }
           }
         }
-#pragma unroll
-        for (int i = 0; i < W; ++i)
-        {
-          double v = rz[i];
-#pragma unroll
-          for (int q = 0; q < i; ++q)
-            v -= Lz[i][q] * zz[q];
-          zz[i] = v * iLz[i];
-        }
-#pragma unroll
-        for (int i = W - 1; i >= 0; --i)
-        {
-          double v = zz[i];
-#pragma unroll
-          for (int q = i + 1; q < W; ++q)
-            v -= Lz[q][i] * zz[q];
-          zz[i] = v * iLz[i];
-        }
-      }
-      // (g) back substitution up the chain
-      double xs[KB];
-#pragma unroll
-      for (int aa = 0; aa < KB; ++aa)
-      {
-        double v = X[aa][0];
-#pragma unroll
+        finish_row();
+        // (f) Schur complement of the chain on the border, W x W solve
+        double Sred[W][W], tred[W];
+  #pragma unroll
         for (int c = 0; c < W; ++c)
-          v -= X[aa][1 + c] * zz[c];
-        xs[aa] = in_chain ? v : 0.0;
-      }
-#pragma unroll 1
-      for (int s = P - 2; s >= 1; --s)
-      {
-        double xn[KB];
-#pragma unroll
-        for (int aa = 0; aa < KB; ++aa)
-          xn[aa] = lane_up1_d<P>(xs[aa], gbase, sub);
-        if (in_chain && sub == s)
         {
-#pragma unroll
+          double v = 0.0;
+  #pragma unroll
+          for (int e = 0; e < KB; ++e)
+            v += Rp[e][1 + c] * X[e][0];
+          tred[c] = v;
+  #pragma unroll
+          for (int c2 = 0; c2 <= c; ++c2)
+          {
+            double u2 = 0.0;
+  #pragma unroll
+            for (int e = 0; e < KB; ++e)
+              u2 += Rp[e][1 + c] * X[e][1 + c2];
+            Sred[c][c2] = u2;
+          }
+        }
+  #pragma unroll
+        for (int c = 0; c < W; ++c)
+        {
+          tred[c] = group_sum_d<P>(tred[c], gbase, sub);
+  #pragma unroll
+          for (int c2 = 0; c2 <= c; ++c2)
+            Sred[c][c2] = group_sum_d<P>(Sred[c][c2], gbase, sub);
+        }
+          {
+          // Cholesky of Z - S (lower), then two triangular solves
+          double Lz[W][W], iLz[W];
+  #pragma unroll
+          for (int c = 0; c < W; ++c)
+          {
+            rz[c] -= tred[c];
+  #pragma unroll
+            for (int c2 = 0; c2 <= c; ++c2)
+              Lz[c][c2] = Z[c][c2] - Sred[c][c2];
+          }
+  #pragma unroll
+          for (int j = 0; j < W; ++j)
+          {
+            double dj = Lz[j][j];
+  #pragma unroll
+            for (int q = 0; q < j; ++q)
+              dj -= Lz[j][q] * Lz[j][q];
+            if (!(dj > 0.0))
+            {
+              status_local = pvalid ? 1 : status_local;
+              dj = 1.0;
+            }
+            const double ilj = rsqrt_d(dj), lj = dj * ilj;
+            Lz[j][j] = lj;
+            iLz[j] = ilj;
+  #pragma unroll
+            for (int i = j + 1; i < W; ++i)
+            {
+              double v = Lz[i][j];
+  #pragma unroll
+              for (int q = 0; q < j; ++q)
+                v -= Lz[i][q] * Lz[j][q];
+              Lz[i][j] = v * ilj;
+            }
+          }
+  #pragma unroll
+          for (int i = 0; i < W; ++i)
+          {
+            double v = rz[i];
+  #pragma unroll
+            for (int q = 0; q < i; ++q)
+              v -= Lz[i][q] * zz[q];
+            zz[i] = v * iLz[i];
+          }
+  #pragma unroll
+          for (int i = W - 1; i >= 0; --i)
+          {
+            double v = zz[i];
+  #pragma unroll
+            for (int q = i + 1; q < W; ++q)
+              v -= Lz[q][i] * zz[q];
+            zz[i] = v * iLz[i];
+          }
+        }
+        // (g) back substitution up the chain
+  #pragma unroll
+        for (int aa = 0; aa < KB; ++aa)
+        {
+          double v = X[aa][0];
+  #pragma unroll
+          for (int c = 0; c < W; ++c)
+            v -= X[aa][1 + c] * zz[c];
+          xs[aa] = in_chain ? v : 0.0;
+        }
+  #ifdef EQLB_EXP_CHAIN3
+        constexpr int SBACK = (P == 8 || P == 16) ? 0 : P - 2;
+  #else
+        constexpr int SBACK = P - 2;
+  #endif
+  #pragma unroll 1
+        for (int s = SBACK; s >= 1; --s)
+        {
+          double xn[KB];
+  #pragma unroll
           for (int aa = 0; aa < KB; ++aa)
-#pragma unroll
-            for (int bb = 0; bb < KB; ++bb)
-              xs[aa] -= Y[aa][bb] * xn[bb];
+            xn[aa] = lane_up1_d<P>(xs[aa], gbase, sub);
+          if (in_chain && sub == s)
+          {
+  #pragma unroll
+            for (int aa = 0; aa < KB; ++aa)
+  #pragma unroll
+              for (int bb = 0; bb < KB; ++bb)
+                xs[aa] -= Y[aa][bb] * xn[bb];
+          }
         }
       }
       // (h) local unknowns of the cell
@@ -1011,6 +1106,11 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         // patch facets are written at their offsets, the DOFs of the outer facet stay zero (the
         // slots are zero-initialised and every row is written once) - no select chain
         const uint32_t loc = info >> INFO_LOCAL_SHIFT;
+#ifdef EQLB_EXP_NOSTORE // timing experiment (wrong results): one LDS store per row instead of 8
+        if (loc != 0u)
+          tile_slots[loc] = ym[0] + yp[0] + ym[K - 1] + yp[K - 1] + Rq[NQ - 1] + ul[NH - 1];
+        else
+#endif
         if (loc != 0u)
         {
           double* o = tile_slots + ((int64_t)(loc - 1) * 3 + ln) * NRT;
@@ -1206,8 +1306,12 @@ int launch_ev_patch_fused(int k, const SeArgs& a, const FusedBins& fb, hipStream
 #ifndef EQLB_TILE_THREADS
 #define EQLB_TILE_THREADS 512
 #endif
-constexpr int TILE_THREADS = EQLB_TILE_THREADS; // 8 waves own 256 cells, 16 waves 512 (k <= 2)
-constexpr int tile_cells_c(int k) { return ((k >= 3) ? 128 : 256) * (TILE_THREADS / 512); }
+#ifndef EQLB_TILE_THREADS_K3
+#define EQLB_TILE_THREADS_K3 512
+#endif
+// k <= 2: 8 waves own 256 cells (two workgroups per CU); k = 3: 128 cells
+constexpr int tile_threads_c(int k) { return (k >= 3) ? EQLB_TILE_THREADS_K3 : EQLB_TILE_THREADS; }
+constexpr int tile_cells_c(int k) { return (k >= 3) ? 128 : 256 * (EQLB_TILE_THREADS / 512); }
 int tile_cells_of(int k) { return tile_cells_c(k); }
 
 // facet-owner table of the EV flush: for the owned cell cl of a tile and its local facet lf the
@@ -1256,8 +1360,9 @@ __device__ __forceinline__ int xcd_remap(int b, int n)
 }
 
 template <int K, int DEG, int MODE>
-__global__ void __launch_bounds__(TILE_THREADS, (K <= 2 ? 4 : 1)) k_se_patch_tiled(const SeArgs a0, const TileArgs ta)
+__global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patch_tiled(const SeArgs a0, const TileArgs ta)
 {
+  constexpr int TILE_THREADS = tile_threads_c(K);
   extern __shared__ double lds[];
   using Z = Sizes<K, DEG, 8>;
   constexpr int NRT = Z::NRT;
@@ -1282,6 +1387,9 @@ __global__ void __launch_bounds__(TILE_THREADS, (K <= 2 ? 4 : 1)) k_se_patch_til
   constexpr int NW = TILE_THREADS / 64;
   int u = wave;
   SeArgs a = a0;
+#ifndef EQLB_TILE_SOLVER
+#define EQLB_TILE_SOLVER 1
+#endif
 #define EQLB_TILE_BIN(B, PP)                                                                        \
   {                                                                                                 \
     const int np = td.npatch[B];                                                                    \
@@ -1290,14 +1398,20 @@ __global__ void __launch_bounds__(TILE_THREADS, (K <= 2 ? 4 : 1)) k_se_patch_til
     a.slot_offset = td.slot_start[B];                                                               \
     a.patch_offset = td.patch_start[B];                                                             \
     for (; u < nwb; u += NW)                                                                        \
-      se_patch_body<K, DEG, PP, 1, 2, 64, MODE>(a, 0, lds, true, (int64_t)u * 64 + lane, sSlots);   \
+      se_patch_body<K, DEG, PP, EQLB_TILE_SOLVER, 2, 64, MODE>(a, 0, lds, true, (int64_t)u * 64 + lane, sSlots); \
     u -= nwb;                                                                                       \
   }
+#ifndef EQLB_EXP_NOBODY
   EQLB_TILE_BIN(0, 4)
   EQLB_TILE_BIN(1, 8)
   EQLB_TILE_BIN(2, 16)
   EQLB_TILE_BIN(3, 32)
   EQLB_TILE_BIN(4, 64)
+#else
+  (void)u;
+  (void)lane;
+  (void)td;
+#endif
 #undef EQLB_TILE_BIN
   __syncthreads();
 
@@ -1393,7 +1507,7 @@ static int launch_tiled_kd(const SeArgs& a, const TileArgs& t, hipStream_t strea
   }
   if (t.ntiles == 0)
     return 0;
-  hipLaunchKernelGGL(kern, dim3((unsigned)t.ntiles), dim3(TILE_THREADS), lds_bytes, stream, a, t);
+  hipLaunchKernelGGL(kern, dim3((unsigned)t.ntiles), dim3(tile_threads_c(K)), lds_bytes, stream, a, t);
   return (hipGetLastError() == hipSuccess) ? 0 : EQLB_ERR_DEVICE;
 }
 
