@@ -39,7 +39,8 @@ __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 
 // ---- DPP lane exchange (VALU data path, no LDS round trip) --------------------------------------
 // gfx9 dpp_ctrl codes: quad_perm 0x00-0xff, row_shl:n 0x100+n, row_shr:n 0x110+n, wave_shl:1 0x130,
-// wave_shr:1 0x138, row_mirror 0x140, row_half_mirror 0x141.  Lanes without a source keep `v`.
+// wave_shr:1 0x138, row_mirror 0x140, row_half_mirror 0x141.  Lanes without a source get 0
+// (bound_ctrl: the destination needs no copy of the old value, one v_mov_dpp per dword).
 #ifndef EQLB_USE_DPP
 #define EQLB_USE_DPP 1
 #endif
@@ -47,12 +48,12 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_d(double v)
 {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 // value of lane - OFF (OFF = 1, 2, 4, 8 within a group of P <= 16 lanes aligned to 16-lane rows;
-// any P for OFF = 1); lanes whose source is outside the row / wave get their own value
+// any P for OFF = 1); lanes whose source is outside the row / wave get 0 (DPP) or their own value
 template <int P, int OFF>
 __device__ __forceinline__ double lane_down_d(double v, int gbase, int sub)
 {

@@ -127,11 +127,22 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   const int64_t slot = a.slot_offset + tl;
   const int64_t patch = a.patch_offset + patch_local;
 
-  // the unused lanes of a patch group hold cell = -1 (the SoA is initialised so): the descriptor
-  // loads do not depend on each other and the gathers of J, G, f wait for ONE load latency
-  const int n = pvalid ? (int)a.pn[patch] : 0;
-  const int32_t cell_raw = pvalid ? a.slot_cell[slot] : -1;
-  const uint32_t info = pvalid ? a.slot_info[slot] : 0u;
+  // Two memory round trips per wave-block: (1) all descriptors of the lane in ONE batch of
+  // independent loads (the unused lanes of a patch group hold cell = -1: the SoA is initialised
+  // so), (2) J, G, f of the cell, issued together as soon as the cell index is there.
+  const int r = a.rhs; // one right-hand side per launch
+  int n = 0;
+  int32_t cell_raw = -1;
+  uint32_t info = 0u;
+  uint8_t flag0 = (uint8_t)PFLAG_INTERIOR, flag = (uint8_t)0;
+  if (pvalid)
+  {
+    n = (int)a.pn[patch];
+    cell_raw = a.slot_cell[slot];
+    info = a.slot_info[slot];
+    flag0 = a.pflag[patch];
+    flag = a.pflag[(int64_t)r * a.npatch_total + patch];
+  }
   const bool active = cell_raw >= 0;
   const int32_t cell = active ? cell_raw : 0;
   const int fm = (info >> INFO_FM_SHIFT) & 3, fp = (info >> INFO_FP_SHIFT) & 3;
@@ -139,14 +150,28 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   const bool rev_m = (info & INFO_REV_M) != 0, rev_p = (info & INFO_REV_P) != 0;
   const int ci = active ? combo_index(fm, fp, rev_m) : 0; // row of the reduced tensors
 
-  const int r = a.rhs; // one right-hand side per launch
-
-  // ---- geometry (cached affine map) ----
+  // ---- geometry (cached affine map) and the DG data of the cell ----
   double J00 = 1.0, J01 = 0.0, J10 = 0.0, J11 = 1.0;
+  double2 gdat[ND];
+  double fdat[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i)
+  {
+    gdat[i] = make_double2(0.0, 0.0);
+    fdat[i] = 0.0;
+  }
   if (active)
   {
     const double2* Jp = reinterpret_cast<const double2*>(a.cellJ + 4 * (int64_t)cell);
+    const double2* gp_ = reinterpret_cast<const double2*>(a.flux_dg + ((int64_t)r * a.ncells + cell) * (ND * 2));
+    const double* fp_ = a.rhs_dg + ((int64_t)r * a.ncells + cell) * ND;
     const double2 j0 = Jp[0], j1 = Jp[1];
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+      gdat[i] = gp_[i];
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+      fdat[i] = fp_[i];
     J00 = j0.x;
     J01 = j0.y;
     J10 = j1.x;
@@ -158,7 +183,6 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   const double pf_p = (fp == 1) ? sgn : -sgn;
 
   // ---- neighbour lanes ----
-  const uint8_t flag0 = pvalid ? a.pflag[patch] : (uint8_t)PFLAG_INTERIOR;
   const bool interior_geo = (flag0 & PFLAG_INTERIOR) != 0;
   const int nf = interior_geo ? n : n + 1;
   const int nn = (n > 0) ? n : 1;
@@ -175,7 +199,6 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   // one right-hand side per launch (a.rhs): a loop over the RHS here makes the compiler hoist the
   // ~70 loop-invariant table loads of phase C above the loop and hold them in ~140 VGPRs
   {
-    const uint8_t flag = pvalid ? a.pflag[(int64_t)r * a.npatch_total + patch] : (uint8_t)0;
     const bool bc0 = (flag & PFLAG_BC0) != 0, bcn = (flag & PFLAG_BCN) != 0;
     const bool d_fixed = bc0 || bcn;
 
@@ -205,8 +228,6 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
           LeG[h] = 0.0;
         if (active)
         {
-          const double2* gp_ = reinterpret_cast<const double2*>(a.flux_dg + ((int64_t)r * a.ncells + cell) * (ND * 2));
-          const double* fp_ = a.rhs_dg + ((int64_t)r * a.ncells + cell) * ND;
           const double* tH = sH + ln * ND * NQ;
           const double* wg = sWG + ci * NH * ND * 2;
           // reference gradient of the hat function of the patch node
@@ -215,8 +236,8 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 #pragma unroll
           for (int i = 0; i < ND; ++i)
           {
-            const double2 g2 = gp_[i];
-            const double fd = detJ * fp_[i];
+            const double2 g2 = gdat[i];
+            const double fd = detJ * fdat[i];
             // detJ * grad hat . G_i = grad_ref hat . (adj G_i)
             const double gg = dh0 * (a00 * g2.x + a01 * g2.y) + dh1 * (a10 * g2.x + a11 * g2.y);
             const double jt0 = J00 * g2.x + J10 * g2.y, jt1 = J01 * g2.x + J11 * g2.y; // J^T G_i
@@ -231,17 +252,18 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       }
       else if (active)
       {
-        const double2* gp_ = reinterpret_cast<const double2*>(a.flux_dg + ((int64_t)r * a.ncells + cell) * (ND * 2));
-        const double* fp_ = a.rhs_dg + ((int64_t)r * a.ncells + cell) * ND;
         const double* tF_m = sF + (fm * 3 + ln) * ND * K;
         const double* tF_p = sF + (fp * 3 + ln) * ND * K;
         const double* tH = sH + ln * ND * NQ;
         const double* tD = sD + ln * ND * 2 * NQ;
+        double fdv[ND], dvg = 0.0;
+        (void)fdv;
+        (void)tD;
 #pragma unroll
         for (int i = 0; i < ND; ++i)
         {
-          const double2 g2 = gp_[i];
-          const double fv = fp_[i];
+          const double2 g2 = gdat[i];
+          const double fv = fdat[i];
           const double gnm = g2.x * num0 + g2.y * num1;
           const double gnp = g2.x * nup0 + g2.y * nup1;
           const double gh0 = a00 * g2.x + a01 * g2.y; // (adj G_i)_X
@@ -253,9 +275,32 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
             gm[j] += tF_m[i * K + j] * gnm;
             gpv[j] += tF_p[i * K + j] * gnp;
           }
+          if constexpr (DEG == 1)
+          {
+            // P1 data: div_ref(adj G) is constant on the cell, D[ln][i][X][q] = d_X psi_i * sum_i' H[ln][i'][q]
+            // (the psi_i sum to one): fold the divergence into the nodal values of detJ f
+            fdv[i] = fd;
+            if (i == 0)
+              dvg = -(gh0 + gh1);
+            else if (i == 1)
+              dvg += gh0;
+            else
+              dvg += gh1;
+          }
+          else
+          {
 #pragma unroll
-          for (int q = 0; q < NQ; ++q)
-            Rq[q] += fd * tH[i * NQ + q] - gh0 * tD[(i * 2 + 0) * NQ + q] - gh1 * tD[(i * 2 + 1) * NQ + q];
+            for (int q = 0; q < NQ; ++q)
+              Rq[q] += fd * tH[i * NQ + q] - gh0 * tD[(i * 2 + 0) * NQ + q] - gh1 * tD[(i * 2 + 1) * NQ + q];
+          }
+        }
+        if constexpr (DEG == 1)
+        {
+#pragma unroll
+          for (int i = 0; i < ND; ++i)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+              Rq[q] += (fdv[i] - dvg) * tH[i * NQ + q];
         }
 #pragma unroll
         for (int j = 0; j < K; ++j)
@@ -783,14 +828,11 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         double am = dpp_d<0x111>(OffC[0][0]);
         if (sub == 0)
           am = 0.0;
+        bool posdef = true; // pivots of the levels, of the last level and of the border system
 #define EQLB_PCR_LEVEL(S)                                                                          \
   if constexpr (P > S)                                                                             \
   {                                                                                                \
-    if (!(b > 0.0))                                                                                \
-    {                                                                                              \
-      status_local = pvalid ? 1 : status_local;                                                    \
-      b = 1.0;                                                                                     \
-    }                                                                                              \
+    posdef = posdef && (b > 0.0);                                                                  \
     const double ib = rcp_d(b);                                                                    \
     const double ib_lo = dpp_d<0x110 + S>(ib), a_lo = dpp_d<0x110 + S>(am);                        \
     const double r0_lo = dpp_d<0x110 + S>(r0), r1_lo = dpp_d<0x110 + S>(r1), r2_lo = dpp_d<0x110 + S>(r2); \
@@ -809,11 +851,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         EQLB_PCR_LEVEL(4)
         EQLB_PCR_LEVEL(8)
 #undef EQLB_PCR_LEVEL
-        if (!(b > 0.0))
-        {
-          status_local = pvalid ? 1 : status_local;
-          b = 1.0;
-        }
+        posdef = posdef && (b > 0.0);
         const double ibf = rcp_d(b);
         const double s0 = r0 * ibf, s1 = r1 * ibf, s2 = r2 * ibf; // A^-1 [rr | bt | c0]
         // (f') Schur complement of the chain on the border [d ; x_0]
@@ -825,26 +863,17 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         Sred[1][1] = group_sum_d<P>(B2 * s2, gbase, sub);
         {
           const double l00 = Z[0][0] - Sred[0][0], l10 = Z[1][0] - Sred[1][0];
-          double d1 = Z[1][1] - Sred[1][1];
-          double d0 = l00;
-          if (!(d0 > 0.0))
-          {
-            status_local = pvalid ? 1 : status_local;
-            d0 = 1.0;
-          }
-          const double i0 = rcp_d(d0);
+          const double i0 = rcp_d(l00);
           const double m = l10 * i0;
-          d1 = __builtin_fma(-m, l10, d1);
-          if (!(d1 > 0.0))
-          {
-            status_local = pvalid ? 1 : status_local;
-            d1 = 1.0;
-          }
+          const double d1 = __builtin_fma(-m, l10, Z[1][1] - Sred[1][1]);
+          posdef = posdef && (l00 > 0.0) && (d1 > 0.0);
           const double q0 = rz[0] - tred[0];
           const double q1 = __builtin_fma(-m, q0, rz[1] - tred[1]);
           zz[1] = q1 * rcp_d(d1);
           zz[0] = __builtin_fma(-l10, zz[1], q0) * i0;
         }
+        if (!posdef && pvalid)
+          status_local = 1;
         const double v = __builtin_fma(-s2, zz[1], __builtin_fma(-s1, zz[0], s0));
         xs[0] = in_chain ? v : 0.0;
       }
