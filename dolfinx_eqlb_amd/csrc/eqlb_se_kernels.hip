@@ -1407,8 +1407,10 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
   if constexpr (MODE == 1)
     for (int i = threadIdx.x; i < Z::NEV; i += TILE_THREADS)
       lds[Z::NTAB + i] = a0.tables[Z::OFF_HG + i];
+#ifndef EQLB_EXP_NOZERO // timing experiment (wrong results)
   for (int i = threadIdx.x; i < TC * 3 * NRT; i += TILE_THREADS)
     sSlots[i] = 0.0;
+#endif
   __syncthreads();
 
   const TileDesc& td = ta.tiles[tile];
@@ -1442,15 +1444,47 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
   (void)td;
 #endif
 #undef EQLB_TILE_BIN
+  const int32_t* cells = ta.tile_cells + (int64_t)tile * TC;
+  const bool conforming = MODE == 1 && ta.facet_owner != nullptr;
+  // flush operands of the broken layout: the old values of flux_hdiv are fetched BEFORE the barrier
+  // (only this tile writes them), so that the two dependent loads hide behind the waves still solving
+  double* x = a0.out + (int64_t)a0.rhs * a0.ncells * NRT;
+  // (two consecutive DOFs per thread where the row length is even: 16-byte loads and stores)
+  constexpr int VW = (NRT % 2 == 0) ? 2 : 1;
+  constexpr int NIT = (TC * NRT / VW + TILE_THREADS - 1) / TILE_THREADS;
+  double xv[NIT][VW];
+  int64_t xi[NIT];
+  if (!conforming)
+  {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+    {
+      const int e = (it * TILE_THREADS + threadIdx.x) * VW;
+      const int cl = e / NRT, i = e - cl * NRT;
+      const int32_t cell = (e < TC * NRT) ? cells[cl] : -1;
+      xi[it] = (cell >= 0) ? (int64_t)cell * NRT + i : -1;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+    {
+      if constexpr (VW == 2)
+      {
+        const double2 t = (xi[it] >= 0) ? *reinterpret_cast<const double2*>(x + xi[it]) : make_double2(0.0, 0.0);
+        xv[it][0] = t.x;
+        xv[it][1] = t.y;
+      }
+      else
+        xv[it][0] = (xi[it] >= 0) ? x[xi[it]] : 0.0;
+    }
+  }
   __syncthreads();
 
-  const int32_t* cells = ta.tile_cells + (int64_t)tile * TC;
-  if (MODE == 1 && ta.facet_owner != nullptr)
+  if (conforming)
   {
     // conforming DOFs (ev/solve_patch.hpp:223-227): facet DOFs by the first cell of the facet,
     // mapped to the global facet frame (T_f = -I / B), interior DOFs by their cell
     constexpr int NI = K * K - K;
-    double* x = a0.out + (int64_t)a0.rhs * ta.ndofs;
+    double* xc = a0.out + (int64_t)a0.rhs * ta.ndofs;
     const int32_t* own = ta.facet_owner + (int64_t)tile * TC * 3;
     for (int e = threadIdx.x; e < TC * 3; e += TILE_THREADS)
     {
@@ -1474,7 +1508,7 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
           g += (rev ? bcoef(j, i) : ((i == j) ? -1.0 : 0.0)) * v[i];
         const int64_t dof = ta.cell_dofs ? (int64_t)ta.cell_dofs[(int64_t)cell * NRT + lf * K + j]
                                          : (int64_t)fct * K + j;
-        x[dof] += g;
+        xc[dof] += g;
       }
     }
     if constexpr (NI > 0)
@@ -1487,34 +1521,32 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
         const double* sl = sSlots + (int64_t)cl * 3 * NRT + 3 * K + i;
         const int64_t dof = ta.cell_dofs ? (int64_t)ta.cell_dofs[(int64_t)cell * NRT + 3 * K + i]
                                          : (int64_t)ta.nfacets * K + (int64_t)cell * NI + i;
-        x[dof] += (sl[0] + sl[NRT]) + sl[2 * NRT];
+        xc[dof] += (sl[0] + sl[NRT]) + sl[2 * NRT];
       }
     return;
   }
 
-  // flush: all reads of the accumulated rows are issued before the first store
-  double* x = a0.out + (int64_t)a0.rhs * a0.ncells * NRT;
-  constexpr int NIT = (TC * NRT + TILE_THREADS - 1) / TILE_THREADS;
-  double xv[NIT];
-  int64_t xi[NIT];
+#ifdef EQLB_EXP_NOFLUSH // timing experiment (wrong results)
+  if (ta.ntiles > 0)
+    return;
+#endif
 #pragma unroll
   for (int it = 0; it < NIT; ++it)
   {
-    const int e = it * TILE_THREADS + threadIdx.x;
-    const int cl = e / NRT, i = e - cl * NRT;
-    const int32_t cell = (e < TC * NRT) ? cells[cl] : -1;
-    xi[it] = (cell >= 0) ? (int64_t)cell * NRT + i : -1;
-    xv[it] = (cell >= 0) ? x[xi[it]] : 0.0;
-  }
-#pragma unroll
-  for (int it = 0; it < NIT; ++it)
-  {
-    const int e = it * TILE_THREADS + threadIdx.x;
+    const int e = (it * TILE_THREADS + threadIdx.x) * VW;
     const int cl = e / NRT, i = e - cl * NRT;
     if (xi[it] >= 0)
     {
       const double* sl = sSlots + (int64_t)cl * 3 * NRT + i;
-      x[xi[it]] = xv[it] + ((sl[0] + sl[NRT]) + sl[2 * NRT]);
+      if constexpr (VW == 2)
+      {
+        double2 t;
+        t.x = xv[it][0] + ((sl[0] + sl[NRT]) + sl[2 * NRT]);
+        t.y = xv[it][1] + ((sl[1] + sl[NRT + 1]) + sl[2 * NRT + 1]);
+        *reinterpret_cast<double2*>(x + xi[it]) = t;
+      }
+      else
+        x[xi[it]] = xv[it][0] + ((sl[0] + sl[NRT]) + sl[2 * NRT]);
     }
   }
 }
