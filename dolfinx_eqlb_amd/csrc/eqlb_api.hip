@@ -205,6 +205,10 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin, eqlb::BuildArgs
   }
   const int32_t ntiles = (nc + TC - 1) / TC;
   rcb_split(items.data(), nc, ntiles, TC);
+  // ascending cell ids inside a tile: the flush of a tile then touches flux_hdiv in long runs
+  for (int32_t t = 0; t < ntiles; ++t)
+    std::sort(items.begin() + (size_t)t * TC, items.begin() + std::min<size_t>((size_t)(t + 1) * TC, nc),
+              [](const TileItem& p, const TileItem& q) { return p.cell < q.cell; });
   std::vector<int32_t> tile_cells((size_t)ntiles * TC, -1), cell_tile(nc), cell_pos(nc);
   for (int32_t p = 0; p < nc; ++p)
   {

@@ -1335,6 +1335,9 @@ int launch_ev_patch_fused(int k, const SeArgs& a, const FusedBins& fb, hipStream
 #ifndef EQLB_TILE_THREADS
 #define EQLB_TILE_THREADS 512
 #endif
+#ifndef EQLB_FLUSH_NT
+#define EQLB_FLUSH_NT 0 // nontemporal loads/stores of flux_hdiv in the tile flush
+#endif
 #ifndef EQLB_TILE_THREADS_K3
 #define EQLB_TILE_THREADS_K3 512
 #endif
@@ -1467,11 +1470,20 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
 #pragma unroll
     for (int it = 0; it < NIT; ++it)
     {
+#ifdef EQLB_EXP_NOXREAD // timing experiment (wrong results)
+      xv[it][0] = xv[it][VW - 1] = 0.0;
+      continue;
+#endif
       if constexpr (VW == 2)
       {
+#if EQLB_FLUSH_NT
+        xv[it][0] = (xi[it] >= 0) ? __builtin_nontemporal_load(x + xi[it]) : 0.0;
+        xv[it][1] = (xi[it] >= 0) ? __builtin_nontemporal_load(x + xi[it] + 1) : 0.0;
+#else
         const double2 t = (xi[it] >= 0) ? *reinterpret_cast<const double2*>(x + xi[it]) : make_double2(0.0, 0.0);
         xv[it][0] = t.x;
         xv[it][1] = t.y;
+#endif
       }
       else
         xv[it][0] = (xi[it] >= 0) ? x[xi[it]] : 0.0;
@@ -1543,7 +1555,16 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
         double2 t;
         t.x = xv[it][0] + ((sl[0] + sl[NRT]) + sl[2 * NRT]);
         t.y = xv[it][1] + ((sl[1] + sl[NRT + 1]) + sl[2 * NRT + 1]);
+#ifdef EQLB_EXP_NOXSTORE // timing experiment (wrong results)
+        if (t.x != 1.2345)
+          continue;
+#endif
+#if EQLB_FLUSH_NT
+        __builtin_nontemporal_store(t.x, x + xi[it]);
+        __builtin_nontemporal_store(t.y, x + xi[it] + 1);
+#else
         *reinterpret_cast<double2*>(x + xi[it]) = t;
+#endif
       }
       else
         x[xi[it]] = xv[it][0] + ((sl[0] + sl[NRT]) + sl[2 * NRT]);
