@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = [
     "eqlb_ev_num_dofs", "eqlb_ev_set_boundary", "eqlb_ev_equilibrate", "eqlb_ev_num_patches",
     "eqlb_ev_last_kernel_ms", "eqlb_se_tiling_info", "eqlb_se_estimate",
     "eqlb_halo_pack", "eqlb_halo_unpack_add", "eqlb_ev_estimate",
+    "eqlb_se_check_status", "eqlb_ev_check_status",
 ]
 
 _lib = None
@@ -189,6 +190,11 @@ class SemiExplicitEquilibrator:
                                          C.c_void_p(flux_hdiv_ptr), C.c_int32(MEM_DEVICE),
                                          C.c_void_p(stream)))
 
+    def check_status(self, stream: int = 0):
+        """After device-memory calls: waits for the stream and raises if a patch system was not
+        positive definite (degenerate cell geometry)."""
+        _check(lib().eqlb_se_check_status(self._h, C.c_void_p(stream)))
+
     def last_kernel_ms(self, which=0):
         return float(lib().eqlb_se_last_kernel_ms(self._h, C.c_int32(which)))
 
@@ -286,6 +292,9 @@ class ConstrainedMinEquilibrator:
         _check(lib().eqlb_ev_equilibrate(self._h, C.c_void_p(flux_dg_ptr), C.c_void_p(rhs_dg_ptr),
                                          C.c_void_p(flux_hdiv_ptr), C.c_int32(MEM_DEVICE),
                                          C.c_void_p(stream)))
+
+    def check_status(self, stream: int = 0):
+        _check(lib().eqlb_ev_check_status(self._h, C.c_void_p(stream)))
 
     def last_kernel_ms(self, which=0):
         return float(lib().eqlb_ev_last_kernel_ms(self._h, C.c_int32(which)))

@@ -1012,6 +1012,23 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
   return EQLB_OK;
 }
 
+int eqlb_se_check_status(eqlb_se_t* h, void* stream_)
+{
+  if (!h)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_check_status: null handle");
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  int32_t status = 0;
+  HIP_TRY(hipMemcpyAsync(&status, h->status, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  if (status)
+  {
+    HIP_TRY(hipMemsetAsync(h->status, 0, sizeof(int32_t), stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return fail(EQLB_ERR_SINGULAR, "patch system not positive definite");
+  }
+  return EQLB_OK;
+}
+
 double eqlb_se_last_kernel_ms(const eqlb_se_t* h, int32_t which)
 {
   // which = b (0..4): patch kernel of bin b (P = 4 << b); 5: slot reduction.
@@ -1331,6 +1348,13 @@ int eqlb_ev_equilibrate(eqlb_ev_t* h, const double* flux_dg, const double* rhs_d
 }
 
 int64_t eqlb_ev_num_patches(const eqlb_ev_t* h) { return h ? h->se->npatch_total : 0; }
+
+int eqlb_ev_check_status(eqlb_ev_t* h, void* stream)
+{
+  if (!h)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_ev_check_status: null handle");
+  return eqlb_se_check_status(h->se, stream);
+}
 
 double eqlb_ev_last_kernel_ms(const eqlb_ev_t* h, int32_t which)
 {

@@ -204,6 +204,14 @@ int32_t eqlb_mesh_max_patch_cells(const eqlb_mesh_t* mesh);
 int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, double* out,
                              int32_t capacity);
 
+/* Device-memory calls (EQLB_MEM_DEVICE) return without synchronising, so a patch system that is not
+ * positive definite (degenerate cell geometry; the matrix does not depend on the data) cannot be
+ * reported by the call itself: the
+ * kernels raise a flag on the device.  eqlb_se_check_status waits for `stream`, reads and clears
+ * the flag: EQLB_OK or EQLB_ERR_SINGULAR (the reference has no such check: Eigen's LLT / LU results
+ * are used unchecked, se/PatchData.hpp:576-663).  Host-memory calls check it themselves. */
+int eqlb_se_check_status(eqlb_se_t* handle, void* stream);
+
 /* With option "timing" = 1 every equilibrate call records HIP events on the launch stream around
  * each kernel (ring of the last 64 calls).  Returns the average device time in ms per launch of
  * kernel `which` over the recorded calls: which = b in 0..4: patch kernel of the bin with
@@ -300,6 +308,7 @@ int eqlb_ev_equilibrate(eqlb_ev_t* handle, const double* flux_dg, const double* 
 int64_t eqlb_ev_num_patches(const eqlb_ev_t* handle);
 /* which = 0: patch kernel (all bins in one launch), 5: reduction to the conforming DOFs */
 double eqlb_ev_last_kernel_ms(const eqlb_ev_t* handle, int32_t which);
+int eqlb_ev_check_status(eqlb_ev_t* handle, void* stream); /* as eqlb_se_check_status */
 
 #ifdef __cplusplus
 }

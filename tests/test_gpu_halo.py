@@ -65,3 +65,44 @@ def test_three_strips_on_one_gpu(oracle_mod, k):
         assert np.abs(got - ref).max() <= 1e-11 * np.abs(ref).max()
         if part.send_cells.size:
             assert np.all(x[part.send_cells] == 0.0)  # ghost rows cleared after packing
+
+
+@pytest.mark.parametrize("ev", [False, True])
+def test_device_calls_report_bad_patches_through_check_status(ev):
+    """Device-memory calls are asynchronous: a patch system that is not positive definite (the
+    matrix depends on the geometry only - here a cell of zero area) raises the device flag,
+    eqlb_*_check_status reports and clears it."""
+    import torch
+    from dolfinx_eqlb_amd import cpp
+    from dolfinx_eqlb_amd.mesh import create_rectangle
+    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    k = 2
+    dev = torch.device("cuda", 0)
+    mesh = create_rectangle(6, 6)
+    ft = facet_types(mesh)
+    G, f = make_compatible_data(mesh, k, ft, seed=3)
+    stream = torch.cuda.current_stream().cuda_stream
+    dG, df = torch.from_numpy(G).to(dev), torch.from_numpy(f).to(dev)
+
+    def sweep(m):
+        eq = cpp.ConstrainedMinEquilibrator(cpp.DeviceMesh(m), k, 1) if ev \
+            else cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(m), k, 1)
+        eq.set_boundary(ft)
+        nout = eq.ndofs if ev else m.ncells * k * (k + 2)
+        x = torch.zeros(nout, dtype=torch.float64, device=dev)
+        eq.equilibrate_device(dG.data_ptr(), df.data_ptr(), x.data_ptr(), stream)
+        return eq, x
+
+    eq, x = sweep(mesh)
+    eq.check_status(stream)  # regular mesh: no complaint
+    assert bool(torch.isfinite(x).all())
+    # collapse one cell: its third vertex is moved onto the line through the other two
+    import copy
+    bad = copy.deepcopy(mesh)
+    c = bad.ncells // 2
+    v = bad.cell_nodes[c]
+    bad.x[v[2], :2] = 0.5 * (bad.x[v[0], :2] + bad.x[v[1], :2])
+    eq, x = sweep(bad)
+    with pytest.raises(RuntimeError):
+        eq.check_status(stream)
+    eq.check_status(stream)  # the flag was cleared
