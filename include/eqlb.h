@@ -206,8 +206,7 @@ int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, dou
 
 /* Device-memory calls (EQLB_MEM_DEVICE) return without synchronising, so a patch system that is not
  * positive definite (degenerate cell geometry; the matrix does not depend on the data) cannot be
- * reported by the call itself: the
- * kernels raise a flag on the device.  eqlb_se_check_status waits for `stream`, reads and clears
+ * reported by the call itself: the kernels raise a flag on the device.  eqlb_se_check_status waits for `stream`, reads and clears
  * the flag: EQLB_OK or EQLB_ERR_SINGULAR (the reference has no such check: Eigen's LLT / LU results
  * are used unchecked, se/PatchData.hpp:576-663).  Host-memory calls check it themselves. */
 int eqlb_se_check_status(eqlb_se_t* handle, void* stream);
