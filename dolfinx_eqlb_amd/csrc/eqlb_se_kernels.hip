@@ -1132,8 +1132,8 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       if constexpr (SCATTER == 2)
       {
         // tiled launch: the row goes to the LDS slot of the owned cell (halo lanes drop it); the two
-        // patch facets are written at their offsets, the DOFs of the outer facet stay zero (the
-        // slots are zero-initialised and every row is written once) - no select chain
+        // patch facets are written at their offsets, the DOFs of the outer facet (always zero) are
+        // not stored - no select chain
         const uint32_t loc = info >> INFO_LOCAL_SHIFT;
 #ifdef EQLB_EXP_NOSTORE // timing experiment (wrong results): one LDS store per row instead of 8
         if (loc != 0u)
@@ -1142,19 +1142,23 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 #endif
         if (loc != 0u)
         {
-          double* o = tile_slots + ((int64_t)(loc - 1) * 3 + ln) * NRT;
+          // packed row: the two facets of the cell that touch the patch node (ascending facet id),
+          // then the interior DOFs; facet f sits at position f - (f > ln)
+          constexpr int NPK = NRT - K;
+          double* o = tile_slots + ((int64_t)(loc - 1) * 3 + ln) * NPK;
+          const int pm = fm - ((fm > ln) ? 1 : 0), pp = fp - ((fp > ln) ? 1 : 0);
 #pragma unroll
           for (int j = 0; j < K; ++j)
           {
-            o[fm * K + j] = pf_m * ym[j];
-            o[fp * K + j] = pf_p * yp[j];
+            o[pm * K + j] = pf_m * ym[j];
+            o[pp * K + j] = pf_p * yp[j];
           }
 #pragma unroll
           for (int q = 0; q < NDIV; ++q)
-            o[3 * K + q] = Rq[1 + q];
+            o[2 * K + q] = Rq[1 + q];
 #pragma unroll
           for (int q = 0; q < NADD; ++q)
-            o[3 * K + NDIV + q] = sgn * ul[1 + 2 * KB + q];
+            o[2 * K + NDIV + q] = sgn * ul[1 + 2 * KB + q];
         }
       }
       double cout[(SCATTER == 2) ? 1 : NRT];
@@ -1341,9 +1345,12 @@ int launch_ev_patch_fused(int k, const SeArgs& a, const FusedBins& fb, hipStream
 #ifndef EQLB_TILE_THREADS_K3
 #define EQLB_TILE_THREADS_K3 512
 #endif
-// k <= 2: 8 waves own 256 cells (two workgroups per CU); k = 3: 128 cells
+// k <= 2: 8 waves own EQLB_TILE_CELLS cells (two workgroups per CU); k = 3: 128 cells
 constexpr int tile_threads_c(int k) { return (k >= 3) ? EQLB_TILE_THREADS_K3 : EQLB_TILE_THREADS; }
-constexpr int tile_cells_c(int k) { return (k >= 3) ? 128 : 256 * (EQLB_TILE_THREADS / 512); }
+#ifndef EQLB_TILE_CELLS
+#define EQLB_TILE_CELLS 480 // 480 cells x 18 packed values + tables: two workgroups per CU (SE and EV)
+#endif
+constexpr int tile_cells_c(int k) { return (k >= 3) ? 128 : EQLB_TILE_CELLS; }
 int tile_cells_of(int k) { return tile_cells_c(k); }
 
 // facet-owner table of the EV flush: for the owned cell cl of a tile and its local facet lf the
@@ -1391,6 +1398,22 @@ __device__ __forceinline__ int xcd_remap(int b, int n)
 #endif
 }
 
+// DOF i of a cell from its three packed (cell, vertex) rows in LDS: row(v0) + row(v1) + row(v2) in this
+// order (the order of the slot path); a facet DOF gets nothing from the vertex opposite to its facet
+template <int K, int NPK>
+__device__ __forceinline__ double packed_sum(const double* rows, int i)
+{
+  if (i >= 3 * K) // interior DOFs: all three rows
+  {
+    const int q = i - K;
+    return (rows[q] + rows[NPK + q]) + rows[2 * NPK + q];
+  }
+  const int f = i / K, j = i - f * K;
+  // rows ln != f, ascending; position of facet f in row ln: f - (f > ln)
+  const int la = (f == 0) ? 1 : 0, lb = (f == 2) ? 1 : 2;
+  return rows[la * NPK + (f - ((f > la) ? 1 : 0)) * K + j] + rows[lb * NPK + (f - ((f > lb) ? 1 : 0)) * K + j];
+}
+
 template <int K, int DEG, int MODE>
 __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patch_tiled(const SeArgs a0, const TileArgs ta)
 {
@@ -1399,6 +1422,7 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
   using Z = Sizes<K, DEG, 8>;
   constexpr int NRT = Z::NRT;
   constexpr int TC = tile_cells_c(K);
+  constexpr int NPK = NRT - K; // packed (cell, vertex) row: without the facet opposite to the vertex
   // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, tiles are numbered along the
   // bisection tree (neighbours in space are neighbours in index); give every XCD one contiguous
   // range of tiles so that the rim cells two tiles share are read through the same L2
@@ -1411,7 +1435,7 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
     for (int i = threadIdx.x; i < Z::NEV; i += TILE_THREADS)
       lds[Z::NTAB + i] = a0.tables[Z::OFF_HG + i];
 #ifndef EQLB_EXP_NOZERO // timing experiment (wrong results)
-  for (int i = threadIdx.x; i < TC * 3 * NRT; i += TILE_THREADS)
+  for (int i = threadIdx.x; i < TC * 3 * NPK; i += TILE_THREADS)
     sSlots[i] = 0.0;
 #endif
   __syncthreads();
@@ -1506,11 +1530,10 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
       const int cl = e / 3, lf = e - 3 * cl;
       const int32_t cell = cells[cl], fct = code >> 1;
       const bool rev = (code & 1) != 0;
-      const double* sl = sSlots + (int64_t)cl * 3 * NRT + lf * K;
       double v[K];
 #pragma unroll
       for (int j = 0; j < K; ++j)
-        v[j] = (sl[j] + sl[NRT + j]) + sl[2 * NRT + j];
+        v[j] = packed_sum<K, NPK>(sSlots + (int64_t)cl * 3 * NPK, lf * K + j);
 #pragma unroll
       for (int j = 0; j < K; ++j)
       {
@@ -1530,10 +1553,9 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
         const int32_t cell = cells[cl];
         if (cell < 0)
           continue;
-        const double* sl = sSlots + (int64_t)cl * 3 * NRT + 3 * K + i;
         const int64_t dof = ta.cell_dofs ? (int64_t)ta.cell_dofs[(int64_t)cell * NRT + 3 * K + i]
                                          : (int64_t)ta.nfacets * K + (int64_t)cell * NI + i;
-        xc[dof] += (sl[0] + sl[NRT]) + sl[2 * NRT];
+        xc[dof] += packed_sum<K, NPK>(sSlots + (int64_t)cl * 3 * NPK, 3 * K + i);
       }
     return;
   }
@@ -1549,12 +1571,12 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
     const int cl = e / NRT, i = e - cl * NRT;
     if (xi[it] >= 0)
     {
-      const double* sl = sSlots + (int64_t)cl * 3 * NRT + i;
+      const double* sl = sSlots + (int64_t)cl * 3 * NPK;
       if constexpr (VW == 2)
       {
         double2 t;
-        t.x = xv[it][0] + ((sl[0] + sl[NRT]) + sl[2 * NRT]);
-        t.y = xv[it][1] + ((sl[1] + sl[NRT + 1]) + sl[2 * NRT + 1]);
+        t.x = xv[it][0] + packed_sum<K, NPK>(sl, i);
+        t.y = xv[it][1] + packed_sum<K, NPK>(sl, i + 1);
 #ifdef EQLB_EXP_NOXSTORE // timing experiment (wrong results)
         if (t.x != 1.2345)
           continue;
@@ -1567,7 +1589,7 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
 #endif
       }
       else
-        x[xi[it]] = xv[it][0] + ((sl[0] + sl[NRT]) + sl[2 * NRT]);
+        x[xi[it]] = xv[it][0] + packed_sum<K, NPK>(sl, i);
     }
   }
 }
@@ -1577,7 +1599,7 @@ static int launch_tiled_kd(const SeArgs& a, const TileArgs& t, hipStream_t strea
 {
   using Z = Sizes<K, DEG, 8>;
   const size_t lds_bytes
-      = sizeof(double) * ((size_t)Z::NTAB + (MODE ? (size_t)Z::NEV : 0) + (size_t)t.tc * 3 * Z::NRT);
+      = sizeof(double) * ((size_t)Z::NTAB + (MODE ? (size_t)Z::NEV : 0) + (size_t)t.tc * 3 * (Z::NRT - K));
   if (lds_bytes > 160 * 1024 || t.tc != tile_cells_c(K))
     return EQLB_ERR_UNSUPPORTED;
   auto kern = k_se_patch_tiled<K, DEG, MODE>;
