@@ -86,9 +86,10 @@ struct FusedBins
   int64_t npatch[MAX_BINS], slot_offset[MAX_BINS], patch_offset[MAX_BINS];
 };
 
-// Tiled launch (EQLB_SCATTER_TILED): a workgroup owns TC cells (a chunk of the Morton-sorted cell
-// list), solves every patch that touches one of them and accumulates the three vertex
-// contributions of its cells in LDS, so neither the slot buffer nor the reduction pass exist.
+// Tiled launch (EQLB_SCATTER_TILED): a workgroup owns TC cells (a leaf of the recursive coordinate
+// bisection of the cell centroids), solves every patch that touches one of them and accumulates the
+// three vertex contributions of its cells in LDS, so neither the slot buffer nor the reduction pass
+// exist.
 struct TileDesc
 {
   int32_t slot_start[MAX_BINS]; // first lane slot of the tile's patches of bin b (multiple of 64)
