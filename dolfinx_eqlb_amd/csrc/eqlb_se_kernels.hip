@@ -916,60 +916,163 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
             }
           }
         };
-        // (e) forward elimination down the chain: lane s receives OffC^T Einv [OffC | Rp] of lane s-1
-  #ifdef EQLB_EXP_CHAIN3 // timing experiment (wrong results): log2(P) elimination steps, no back substitution
-        constexpr int SEND = (P == 8) ? 5 : ((P == 16) ? 6 : P);
-  #else
-        constexpr int SEND = P;
-  #endif
-  #pragma unroll 1
-        for (int s = 2; s < SEND; ++s)
+        constexpr bool BLOCK_PCR = KB == 2 && P <= 16 && EQLB_CHAIN_PCR;
+        if constexpr (BLOCK_PCR)
         {
-          finish_row();
-          double P1[KB][KB], P2[KB][1 + W];
+          // (e') RT_3: block parallel cyclic reduction (2 x 2 blocks, right-hand sides
+          // [rr | column of d | two columns of x_0]), log2(P) levels instead of P - 2 hand-offs down and
+          // P - 2 up.  Row i:  A_i x_{i-s} + D_i x_i + A_{i+s}^T x_{i+s} = R_i, A_i = coupling to row
+          // i - s (level matrices stay symmetric).  Rows outside the chain are identity rows, the
+          // couplings across the ends are exact zeros (see the scalar variant above).
+          double D00 = Dp[0][0], D01 = Dp[0][1], D11 = Dp[1][1];
+          double A[KB][KB], R[KB][1 + W], Bo[KB][W];
   #pragma unroll
           for (int aa = 0; aa < KB; ++aa)
           {
   #pragma unroll
-            for (int bb = 0; bb < KB; ++bb)
+            for (int e = 0; e < KB; ++e)
             {
-              double v = 0.0;
-  #pragma unroll
-              for (int e = 0; e < KB; ++e)
-                v += OffC[e][aa] * Y[e][bb];
-              P1[aa][bb] = v;
+              const double v = dpp_d<0x111>(OffC[e][aa]); // A_i = OffC_{i-1}^T
+              A[aa][e] = (sub == 0) ? 0.0 : v;
             }
   #pragma unroll
             for (int c = 0; c < 1 + W; ++c)
-            {
-              double v = 0.0;
+              R[aa][c] = Rp[aa][c];
   #pragma unroll
-              for (int e = 0; e < KB; ++e)
-                v += OffC[e][aa] * X[e][c];
-              P2[aa][c] = v;
-            }
+            for (int c = 0; c < W; ++c)
+              Bo[aa][c] = Rp[aa][1 + c];
           }
-          const bool take = in_chain && sub == s;
+          bool posdef = true;
+          double I00, I01, I11; // inverse of the diagonal block
+          auto invert = [&]() {
+            const double det = __builtin_fma(D00, D11, -D01 * D01);
+            posdef = posdef && (D00 > 0.0) && (det > 0.0);
+            const double id = rcp_d(det);
+            I00 = D11 * id;
+            I11 = D00 * id;
+            I01 = -D01 * id;
+          };
+  #define EQLB_BPCR_LEVEL(S)                                                                          \
+    if constexpr (P > S)                                                                              \
+    {                                                                                                 \
+      invert();                                                                                       \
+      const double l00 = dpp_d<0x110 + S>(I00), l01 = dpp_d<0x110 + S>(I01), l11 = dpp_d<0x110 + S>(I11); \
+      const double h00 = dpp_d<0x100 + S>(I00), h01 = dpp_d<0x100 + S>(I01), h11 = dpp_d<0x100 + S>(I11); \
+      double Al[KB][KB], Ah[KB][KB], Rl[KB][1 + W], Rh[KB][1 + W];                                    \
+      _Pragma("unroll") for (int aa = 0; aa < KB; ++aa)                                               \
+      {                                                                                               \
+        _Pragma("unroll") for (int e = 0; e < KB; ++e)                                                \
+        {                                                                                             \
+          Al[aa][e] = dpp_d<0x110 + S>(A[aa][e]);                                                     \
+          const double t = dpp_d<0x100 + S>(A[aa][e]);                                                \
+          Ah[aa][e] = (P < 16 && !(sub + S < P)) ? 0.0 : t; /* row i + S of ANOTHER group */          \
+        }                                                                                             \
+        _Pragma("unroll") for (int c = 0; c < 1 + W; ++c)                                             \
+        {                                                                                             \
+          Rl[aa][c] = dpp_d<0x110 + S>(R[aa][c]);                                                     \
+          Rh[aa][c] = dpp_d<0x100 + S>(R[aa][c]);                                                     \
+        }                                                                                             \
+      }                                                                                               \
+      /* al = A Dinv(i-S), ga = A(i+S)^T Dinv(i+S) */                                                 \
+      double al[KB][KB], ga[KB][KB];                                                                  \
+      _Pragma("unroll") for (int aa = 0; aa < KB; ++aa)                                               \
+      {                                                                                               \
+        al[aa][0] = A[aa][0] * l00 + A[aa][1] * l01;                                                  \
+        al[aa][1] = A[aa][0] * l01 + A[aa][1] * l11;                                                  \
+        ga[aa][0] = Ah[0][aa] * h00 + Ah[1][aa] * h01;                                                \
+        ga[aa][1] = Ah[0][aa] * h01 + Ah[1][aa] * h11;                                                \
+      }                                                                                               \
+      D00 -= al[0][0] * A[0][0] + al[0][1] * A[0][1] + ga[0][0] * Ah[0][0] + ga[0][1] * Ah[1][0];     \
+      D01 -= al[0][0] * A[1][0] + al[0][1] * A[1][1] + ga[0][0] * Ah[0][1] + ga[0][1] * Ah[1][1];     \
+      D11 -= al[1][0] * A[1][0] + al[1][1] * A[1][1] + ga[1][0] * Ah[0][1] + ga[1][1] * Ah[1][1];     \
+      _Pragma("unroll") for (int aa = 0; aa < KB; ++aa)                                               \
+      {                                                                                               \
+        _Pragma("unroll") for (int c = 0; c < 1 + W; ++c)                                             \
+          R[aa][c] -= al[aa][0] * Rl[0][c] + al[aa][1] * Rl[1][c] + ga[aa][0] * Rh[0][c] + ga[aa][1] * Rh[1][c]; \
+        const double n0 = -(al[aa][0] * Al[0][0] + al[aa][1] * Al[1][0]);                             \
+        const double n1 = -(al[aa][0] * Al[0][1] + al[aa][1] * Al[1][1]);                             \
+        A[aa][0] = n0;                                                                                \
+        A[aa][1] = n1;                                                                                \
+      }                                                                                               \
+    }
+          EQLB_BPCR_LEVEL(1)
+          EQLB_BPCR_LEVEL(2)
+          EQLB_BPCR_LEVEL(4)
+          EQLB_BPCR_LEVEL(8)
+  #undef EQLB_BPCR_LEVEL
+          invert();
+          if (!posdef && pvalid)
+            status_local = 1;
+  #pragma unroll
+          for (int c = 0; c < 1 + W; ++c)
+          {
+            X[0][c] = I00 * R[0][c] + I01 * R[1][c];
+            X[1][c] = I01 * R[0][c] + I11 * R[1][c];
+          }
+          // the border reduction below pairs the ORIGINAL coupling columns with the solution
   #pragma unroll
           for (int aa = 0; aa < KB; ++aa)
-          {
   #pragma unroll
-            for (int bb = 0; bb < KB; ++bb)
-            {
-              const double v = lane_down_d<P, 1>(P1[aa][bb], gbase, sub);
-              if (take)
-                Dp[aa][bb] -= v;
-            }
-  #pragma unroll
-            for (int c = 0; c < 1 + W; ++c)
-            {
-              const double v = lane_down_d<P, 1>(P2[aa][c], gbase, sub);
-              if (take)
-                Rp[aa][c] -= v;
-            }
-          }
+            for (int c = 0; c < W; ++c)
+              Rp[aa][1 + c] = Bo[aa][c];
         }
-        finish_row();
+        else
+        {
+          // (e) forward elimination down the chain: lane s receives OffC^T Einv [OffC | Rp] of lane s-1
+    #ifdef EQLB_EXP_CHAIN3 // timing experiment (wrong results): log2(P) elimination steps, no back substitution
+          constexpr int SEND = (P == 8) ? 5 : ((P == 16) ? 6 : P);
+    #else
+          constexpr int SEND = P;
+    #endif
+    #pragma unroll 1
+          for (int s = 2; s < SEND; ++s)
+          {
+            finish_row();
+            double P1[KB][KB], P2[KB][1 + W];
+    #pragma unroll
+            for (int aa = 0; aa < KB; ++aa)
+            {
+    #pragma unroll
+              for (int bb = 0; bb < KB; ++bb)
+              {
+                double v = 0.0;
+    #pragma unroll
+                for (int e = 0; e < KB; ++e)
+                  v += OffC[e][aa] * Y[e][bb];
+                P1[aa][bb] = v;
+              }
+    #pragma unroll
+              for (int c = 0; c < 1 + W; ++c)
+              {
+                double v = 0.0;
+    #pragma unroll
+                for (int e = 0; e < KB; ++e)
+                  v += OffC[e][aa] * X[e][c];
+                P2[aa][c] = v;
+              }
+            }
+            const bool take = in_chain && sub == s;
+    #pragma unroll
+            for (int aa = 0; aa < KB; ++aa)
+            {
+    #pragma unroll
+              for (int bb = 0; bb < KB; ++bb)
+              {
+                const double v = lane_down_d<P, 1>(P1[aa][bb], gbase, sub);
+                if (take)
+                  Dp[aa][bb] -= v;
+              }
+    #pragma unroll
+              for (int c = 0; c < 1 + W; ++c)
+              {
+                const double v = lane_down_d<P, 1>(P2[aa][c], gbase, sub);
+                if (take)
+                  Rp[aa][c] -= v;
+              }
+            }
+          }
+          finish_row();
+        }
         // (f) Schur complement of the chain on the border, W x W solve
         double Sred[W][W], tred[W];
   #pragma unroll
@@ -1069,7 +1172,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         constexpr int SBACK = P - 2;
   #endif
   #pragma unroll 1
-        for (int s = SBACK; s >= 1; --s)
+        for (int s = BLOCK_PCR ? 0 : SBACK; s >= 1; --s)
         {
           double xn[KB];
   #pragma unroll
