@@ -1446,14 +1446,17 @@ int launch_ev_patch_fused(int k, const SeArgs& a, const FusedBins& fb, hipStream
 #define EQLB_FLUSH_NT 0 // nontemporal loads/stores of flux_hdiv in the tile flush
 #endif
 #ifndef EQLB_TILE_THREADS_K3
-#define EQLB_TILE_THREADS_K3 512
+#define EQLB_TILE_THREADS_K3 256 // the k = 3 body runs at 2 waves/SIMD: two 4-wave workgroups per CU
 #endif
-// k <= 2: 8 waves own EQLB_TILE_CELLS cells (two workgroups per CU); k = 3: 128 cells
+// k <= 2: 8 waves own EQLB_TILE_CELLS cells (two workgroups per CU); k = 3: 4 waves, EQLB_TILE_CELLS_K3 cells
 constexpr int tile_threads_c(int k) { return (k >= 3) ? EQLB_TILE_THREADS_K3 : EQLB_TILE_THREADS; }
 #ifndef EQLB_TILE_CELLS
 #define EQLB_TILE_CELLS 480 // 480 cells x 18 packed values + tables: two workgroups per CU (SE and EV)
 #endif
-constexpr int tile_cells_c(int k) { return (k >= 3) ? 128 : EQLB_TILE_CELLS; }
+#ifndef EQLB_TILE_CELLS_K3
+#define EQLB_TILE_CELLS_K3 160 // 160 cells x 36 packed values + 30 KB of tables: two workgroups per CU
+#endif
+constexpr int tile_cells_c(int k) { return (k >= 3) ? EQLB_TILE_CELLS_K3 : EQLB_TILE_CELLS; }
 int tile_cells_of(int k) { return tile_cells_c(k); }
 
 // facet-owner table of the EV flush: for the owned cell cl of a tile and its local facet lf the
