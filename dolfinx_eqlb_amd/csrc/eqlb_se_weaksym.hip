@@ -863,8 +863,11 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
   wave_sync();
 
   // B_k of this lane's cell: Be[h][j], k = 0: int (Phi_h)_y psi_j, k = 1: -int (Phi_h)_x psi_j
+  // Columns of this lane: point 0 (the patch node; the same in every lane) and ring point sub + 1.
+  // B_k of this lane's cell: Be[h][j], k = 0: int (Phi_h)_y psi_j, k = 1: -int (Phi_h)_x psi_j
+  const bool own_pt = sub + 1 < npnt; // the lane owns ring point sub + 1
   auto form_Y = [&](int k, double (&y0)[DM], double (&y1)[DM]) {
-    // assemble B_k into Yb, then columns c = sub and sub + P: y = L^-1 b
+    // assemble B_k into Yb, then the two columns: y = L^-1 b
     for (int e = sub; e < DM * LDB; e += P)
       Yb[e] = 0.0;
     wave_sync();
@@ -882,12 +885,11 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
         }
     }
     wave_sync();
-    const bool h0 = sub < npnt, h1 = sub + P < npnt;
 #pragma unroll
     for (int i = 0; i < DM; ++i)
     {
-      y0[i] = (h0 && i < dim) ? Yb[i * LDB + sub] : 0.0;
-      y1[i] = (h1 && i < dim) ? Yb[i * LDB + sub + P] : 0.0;
+      y0[i] = Yb[i * LDB];
+      y1[i] = own_pt ? Yb[i * LDB + sub + 1] : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < DM; ++i)
@@ -901,41 +903,24 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
         t1 -= l * y1[q];
       }
       const double d = Dg[i];
-      y0[i] = (i < dim) ? t0 * d : 0.0;
-      y1[i] = (i < dim) ? t1 * d : 0.0;
+      y0[i] = t0 * d; // rows >= dim of the factor are identity rows, the data there is zero
+      y1[i] = t1 * d;
     }
   };
 
-  // ---- Schur system [C | rhs] in registers: rows r = sub and r = sub + P ----
-  double r0[DCM + 1], r1[DCM + 1];
+  // ---- Schur system in registers: row of ring point sub + 1 in its lane, row of point 0 in every
+  // lane.  S = sum_k Y_k^T Y_k is symmetric positive (semi-)definite, so no pivoting is needed
+  // (the reference factorises the bordered indefinite system with partial pivoting,
+  // se/PatchData.hpp:598-663; same solution):
+  //   boundary patches (essnt_primal):  S gamma = -R
+  //   interior patches: S 1 = 0 (the patch functions are divergence free with zero normal trace),
+  //   the mean-value row fixes the constant: lambda = sum R / sum M, gamma_0 := 0 in
+  //   S gamma = -(R - lambda M), then gamma -= (M . gamma) / sum M.
+  constexpr int NPT = P + 1; // points of a patch: the node + at most P ring points
+  double rv[NPT + 1], rn[NPT + 1]; // [S row | rhs] of the ring point / of the node
 #pragma unroll
-  for (int j = 0; j <= DCM; ++j)
-    r0[j] = r1[j] = 0.0;
-  if (pvalid)
-  {
-    if (meanvalue)
-    {
-      // multiplier row / column: int psi_j over the patch
-#pragma unroll
-      for (int j = 0; j < DCM; ++j)
-      {
-        if (j == npnt)
-        {
-          r0[j] = (sub < npnt) ? Mv[sub] : 0.0;
-          r1[j] = (sub + P < npnt) ? Mv[sub + P] : 0.0;
-        }
-        if (j < npnt)
-        {
-          if (sub == npnt)
-            r0[j] = Mv[j];
-          if (sub + P == npnt)
-            r1[j] = Mv[j];
-        }
-      }
-    }
-    r0[DCM] = (sub < npnt) ? Rg[sub] : 0.0;
-    r1[DCM] = (sub + P < npnt) ? Rg[sub + P] : 0.0;
-  }
+  for (int j = 0; j <= NPT; ++j)
+    rv[j] = rn[j] = 0.0;
   double ys0[2][DM], ys1[2][DM]; // the lane's columns of Y_0, Y_1 (kept for the back substitution)
 #pragma unroll
   for (int k = 0; k < 2; ++k)
@@ -943,133 +928,142 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
     double(&y0)[DM] = ys0[k];
     double(&y1)[DM] = ys1[k];
     form_Y(k, y0, y1);
-    // publish the substituted columns, then C[r][c] -= y_r . y_c for the lane's rows
+    // publish the substituted columns, then S[r][c] += y_r . y_c for the lane's two rows
 #pragma unroll
     for (int i = 0; i < DM; ++i)
     {
-      if (sub < npnt && i < dim)
-        Yb[i * LDB + sub] = y0[i];
-      if (sub + P < npnt && i < dim)
-        Yb[i * LDB + sub + P] = y1[i];
+      if (sub == 0)
+        Yb[i * LDB] = y0[i];
+      if (own_pt)
+        Yb[i * LDB + sub + 1] = y1[i];
     }
     wave_sync();
 #pragma unroll
-    for (int c = 0; c < W::NPM; ++c)
+    for (int c = 0; c < NPT; ++c)
     {
-      if (c < npnt)
-      {
-        double t0 = 0.0, t1 = 0.0;
+      double t0 = 0.0, t1 = 0.0;
 #pragma unroll
-        for (int i = 0; i < DM; ++i)
-        {
-          const double yc = (i < dim) ? Yb[i * LDB + c] : 0.0;
-          t0 += y0[i] * yc;
-          t1 += y1[i] * yc;
-        }
-        r0[c] -= t0;
-        r1[c] -= t1;
+      for (int i = 0; i < DM; ++i)
+      {
+        const double yc = Yb[i * LDB + c]; // columns >= npnt are zero
+        t0 += y0[i] * yc;
+        t1 += y1[i] * yc;
       }
+      // pin the two dot products here: otherwise the compiler sinks the FMAs of all columns below
+      // the LDS reads of all columns (180 live VGPRs, spilled)
+      asm volatile("" : "+v"(t0), "+v"(t1));
+      rn[c] += t0;
+      rv[c] += t1;
     }
     wave_sync();
   }
-
-  // ---- distributed LU with partial pivoting (as in k_se_weaksym) ----
-  double gam[DCM];
+  double gam[NPT], g_own = 0.0;
+  int sing = 0;
+  {
+    double m_own = own_pt ? Mv[sub + 1] : 0.0;
+    const double m0 = pvalid ? Mv[0] : 1.0;
+    double q_own = own_pt ? -Rg[sub + 1] : 0.0, q0 = pvalid ? -Rg[0] : 0.0; // right-hand side -R
+    const double sum_m = m0 + group_sum_d<P>(m_own, gb, sub);
+    double lam = 0.0;
+    if (meanvalue)
+    {
+      const double sum_q = q0 + group_sum_d<P>(q_own, gb, sub);
+      lam = sum_q * rcp_d(sum_m); // = -lambda
+      q_own -= lam * m_own;
+#pragma unroll
+      for (int c = 0; c < NPT; ++c)
+        rn[c] = (c == 0) ? 1.0 : 0.0; // gamma_0 := 0
+      rv[0] = 0.0;
+      q0 = 0.0;
+    }
+    rv[NPT] = q_own;
+    rn[NPT] = q0;
+    if (!own_pt) // lanes without a ring point: identity row
+    {
+#pragma unroll
+      for (int c = 0; c <= NPT; ++c)
+        rv[c] = (c == sub + 1) ? 1.0 : 0.0;
+    }
+    if (!pvalid)
+    {
+#pragma unroll
+      for (int c = 0; c <= NPT; ++c)
+        rn[c] = (c == 0) ? 1.0 : 0.0;
+    }
 #ifdef EQLB_WSL_SKIP_LU // timing experiment (wrong results)
 #pragma unroll
-  for (int c = 0; c < DCM; ++c)
-    gam[c] = r0[c] + r1[c];
+    for (int c = 0; c < NPT; ++c)
+      gam[c] = rv[c] + rn[c];
+    g_own = rv[NPT];
 #else
-  {
-    bool free0 = sub < dim_c, free1 = sub + P < dim_c;
-    int prow[DCM];
-#pragma unroll
-    for (int c = 0; c < DCM; ++c)
+    // elimination without pivoting: pivot 0 is the replicated node row, pivot p the row of lane p - 1
     {
-      prow[c] = 0;
-      if (c < dim_c)
-      {
-        double bv = free0 ? fabs(r0[c]) : -1.0;
-        int br = sub;
-        const double v1 = free1 ? fabs(r1[c]) : -1.0;
-        if (v1 > bv)
-        {
-          bv = v1;
-          br = sub + P;
-        }
+      if (!(rn[0] > 0.0))
+        sing = 1;
+      const double f = rv[0] * rcp_d(rn[0]);
 #pragma unroll
-        for (int off = 1; off < P; off <<= 1)
-        {
-          const double ov = __shfl(bv, gb + (sub ^ off), 64);
-          const int orow = __shfl(br, gb + (sub ^ off), 64);
-          if (ov > bv || (ov == bv && orow < br))
-          {
-            bv = ov;
-            br = orow;
-          }
-        }
-        if (!(bv > 0.0))
-          status_local = pvalid ? 1 : status_local;
-        prow[c] = br;
-        const int owner = gb + (br % P);
-        const bool second = br >= P;
-        double pr[DCM + 1];
-#pragma unroll
-        for (int j = c; j <= DCM; ++j)
-          pr[j] = __shfl(second ? r1[j] : r0[j], owner, 64);
-        const double ip = rcp_d((pr[c] != 0.0) ? pr[c] : 1.0);
-        if (br == sub)
-          free0 = false;
-        if (br == sub + P)
-          free1 = false;
-        const double f0 = free0 ? r0[c] * ip : 0.0, f1 = free1 ? r1[c] * ip : 0.0;
-#pragma unroll
-        for (int j = c; j <= DCM; ++j)
-        {
-          r0[j] -= f0 * pr[j];
-          r1[j] -= f1 * pr[j];
-        }
-      }
+      for (int c = 1; c <= NPT; ++c)
+        rv[c] -= f * rn[c];
     }
 #pragma unroll
-    for (int c = DCM - 1; c >= 0; --c)
+    for (int p = 1; p < NPT; ++p)
     {
-      gam[c] = 0.0;
-      if (c < dim_c)
-      {
-        const int br = prow[c];
-        const bool second = br >= P;
-        double t = second ? r1[DCM] : r0[DCM];
+      double pr[NPT + 1];
 #pragma unroll
-        for (int j = c + 1; j < DCM; ++j)
-          t -= (second ? r1[j] : r0[j]) * gam[j];
-        const double d = second ? r1[c] : r0[c];
-        t *= rcp_d((d != 0.0) ? d : 1.0);
-        gam[c] = __shfl(t, gb + (br % P), 64);
-      }
+      for (int c = p; c <= NPT; ++c)
+        pr[c] = __shfl(rv[c], gb + p - 1, 64);
+      if (!(pr[p] > 0.0))
+        sing = 1;
+      const double f = (sub + 1 > p) ? rv[p] * rcp_d(pr[p]) : 0.0;
+#pragma unroll
+      for (int c = p + 1; c <= NPT; ++c)
+        rv[c] -= f * pr[c];
     }
-  }
+    // back substitution: gamma replicated in every lane
+#pragma unroll
+    for (int p = NPT - 1; p >= 1; --p)
+    {
+      double t = rv[NPT];
+#pragma unroll
+      for (int c = p + 1; c < NPT; ++c)
+        t -= rv[c] * gam[c];
+      t *= rcp_d(rv[p]); // the row of lane p - 1 (identity rows: pivot 1, right-hand side 0)
+      if (sub + 1 == p)
+        g_own = t;
+      gam[p] = __shfl(t, gb + p - 1, 64);
+    }
+    {
+      double t = rn[NPT];
+#pragma unroll
+      for (int c = 1; c < NPT; ++c)
+        t -= rn[c] * gam[c];
+      gam[0] = t * rcp_d(rn[0]);
+    }
 #endif
+    if (meanvalue)
+    {
+      const double shift = (m0 * gam[0] + group_sum_d<P>(m_own * g_own, gb, sub)) * rcp_d(sum_m);
+#pragma unroll
+      for (int c = 0; c < NPT; ++c)
+        gam[c] -= shift;
+      g_own -= shift;
+    }
+    if (!own_pt)
+      g_own = 0.0;
+  }
+  if (sing && pvalid)
+    status_local = 1;
 
-  // ---- u_k = -L^-T (Y_k gamma): partial sums over the lane's columns, group sum, back substitution ----
+  // ---- u_k = -L^-T (Y_k gamma): node column (every lane the same) + group sum over the ring columns ----
 #pragma unroll
   for (int k = 0; k < 2; ++k)
   {
     const double(&y0)[DM] = ys0[k];
     const double(&y1)[DM] = ys1[k];
-    double g0 = 0.0, g1 = 0.0; // gamma of the lane's columns
-#pragma unroll
-    for (int c = 0; c < W::NPM; ++c)
-    {
-      if (c == sub)
-        g0 = gam[c];
-      if (c == sub + P)
-        g1 = gam[c];
-    }
     double w[DM];
 #pragma unroll
     for (int i = 0; i < DM; ++i)
-      w[i] = -group_sum_d<P>(y0[i] * g0 + y1[i] * g1, gb, sub);
+      w[i] = -(y0[i] * gam[0] + group_sum_d<P>(y1[i] * g_own, gb, sub));
 #pragma unroll
     for (int i = DM - 1; i >= 0; --i)
     {
@@ -1086,6 +1080,7 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
         Wg[k * DM + i] = w[i];
     wave_sync();
   }
+
 
   // ---- back-map and add to the slot rows (se/solve_patch_weaksym.hpp:189-232) ----
   if (active)
