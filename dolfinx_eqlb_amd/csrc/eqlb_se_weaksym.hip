@@ -674,11 +674,13 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
 }
 
 // ---- lean variant: k = 2, patches of up to 8 cells, NO flux BCs on the stress rows -----------------
-// (the benchmark / pure-Dirichlet case).  Same mathematics, a fraction of the LDS: the Cholesky
-// factor of A (<= 9 x 9) is computed in registers and parked in LDS, the Schur system lives in
-// registers from the start (rows r = sub, sub + P, the layout of the distributed LU), Y_k = L^-1 B_k
-// is formed per stress row in one 9 x 10 buffer; every lane keeps its own columns in registers.
-// 184 doubles of LDS per patch instead of 438 -> about three times the resident waves.
+// (the benchmark / pure-Dirichlet case).  Same solution, a fraction of the LDS and no pivoting: the
+// Cholesky factor of A (<= 9 x 9) is computed in registers and parked in LDS, Y_k = L^-1 B_k is formed
+// per stress row in one 9 x 10 buffer (every lane keeps the node column and the column of its ring
+// point), the Schur matrix S = sum_k Y_k^T Y_k is symmetric positive (semi-)definite and is eliminated
+// without pivoting - row of ring point sub + 1 in lane sub, row of the patch node in every lane, the
+// mean-value multiplier of interior patches analytically (see below).
+// 184 doubles of LDS per patch instead of 438.
 #ifndef EQLB_WS_LEAN_WAVES
 #define EQLB_WS_LEAN_WAVES 2
 #endif
@@ -704,7 +706,7 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
 {
   using W = WsLean<P>;
   using Z = typename W::Z;
-  constexpr int K = 2, KB = 1, NH = W::NH, NRT = W::NRT, NTE = W::NTE, DM = W::DM, DCM = W::DCM, LDB = W::LDB;
+  constexpr int K = 2, KB = 1, NH = W::NH, NRT = W::NRT, NTE = W::NTE, DM = W::DM, LDB = W::LDB;
   static_assert(DM <= 9 && NH == 3, "lean weak-symmetry kernel: k = 2, at most 8 cells");
 
   extern __shared__ double lds[];
@@ -726,20 +728,45 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
   const bool pvalid = patch_local < a.npatch;
   const int64_t slot = a.slot_offset + patch_local * P + sub;
   const int64_t patch = a.patch_offset + patch_local;
-  const int n = pvalid ? (int)a.pn[patch] : 0;
-  const bool active = pvalid && sub < n;
-  const int32_t cell = active ? a.slot_cell[slot] : 0;
-  const uint32_t info = active ? a.slot_info[slot] : 0u;
+  // two load batches: (1) the descriptors of the lane (independent loads; the unused lanes of a
+  // patch group hold cell = -1), (2) J and the two stress rows of the cell
+  int n = 0;
+  int32_t cell_raw = -1;
+  uint32_t info = 0u;
+  uint8_t flag0 = (uint8_t)PFLAG_INTERIOR;
+  if (pvalid)
+  {
+    n = (int)a.pn[patch];
+    cell_raw = a.slot_cell[slot];
+    info = a.slot_info[slot];
+    flag0 = a.pflag[patch];
+  }
+  const bool active = cell_raw >= 0;
+  const int32_t cell = active ? cell_raw : 0;
   const int fm = (info >> INFO_FM_SHIFT) & 3, fp = (info >> INFO_FP_SHIFT) & 3;
   const int ln = (info >> INFO_LN_SHIFT) & 3;
   const bool rev_m = (info & INFO_REV_M) != 0;
   const int ci = active ? combo_index(fm, fp, rev_m) : 0;
 
   double J[2][2] = {{1.0, 0.0}, {0.0, 1.0}};
+  double* srow[2] = {nullptr, nullptr};
+  double2 sv[2][W::NRT / 2]; // the patch-local stress rows sigma_a of the cell
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int i = 0; i < W::NRT / 2; ++i)
+      sv[r][i] = make_double2(0.0, 0.0);
   if (active)
   {
     const double2* Jp = reinterpret_cast<const double2*>(a.cellJ + 4 * (int64_t)cell);
+    srow[0] = a.out + (((int64_t)0 * a.ncells + cell) * 3 + ln) * W::NRT;
+    srow[1] = a.out + (((int64_t)1 * a.ncells + cell) * 3 + ln) * W::NRT;
     const double2 j0 = Jp[0], j1 = Jp[1];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int i = 0; i < W::NRT / 2; ++i)
+        sv[r][i] = reinterpret_cast<const double2*>(srow[r])[i];
     J[0][0] = j0.x;
     J[0][1] = j0.y;
     J[1][0] = j1.x;
@@ -749,7 +776,6 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
   const double sgn = (detJ > 0.0) ? 1.0 : -1.0;
   const double pf_m = (fm == 1) ? sgn : -sgn, pf_p = (fp == 1) ? sgn : -sgn;
 
-  const uint8_t flag0 = pvalid ? a.pflag[patch] : (uint8_t)PFLAG_INTERIOR;
   const bool interior = (flag0 & PFLAG_INTERIOR) != 0;
   const int nf = interior ? n : n + 1;
   const int nn = (n > 0) ? n : 1;
@@ -757,7 +783,6 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
   const int dim = pvalid ? 1 + nf : 0;
   const int npnt = nf + 1;
   const bool meanvalue = interior; // no flux BCs: boundary patches are of type essnt_primal
-  const int dim_c = pvalid ? (meanvalue ? npnt + 1 : npnt) : 0;
 
   double* Lg = sG + (tid / P) * W::GROUP;
   double* Dg = Lg + W::OFF_D;
@@ -785,10 +810,9 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
   for (int e = sub; e < W::GROUP; e += P)
     Lg[e] = 0.0;
   wave_sync();
-  double* srow[2] = {nullptr, nullptr};
   if (active)
   {
-    const double ia = 1.0 / fabs(detJ);
+    const double ia = rcp_d(fabs(detJ));
     const double g0 = (J[0][0] * J[0][0] + J[1][0] * J[1][0]) * ia,
                  g1 = (J[0][0] * J[0][1] + J[1][0] * J[1][1]) * ia,
                  g2 = (J[0][1] * J[0][1] + J[1][1] * J[1][1]) * ia;
@@ -803,13 +827,12 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
         if (gi[h] >= gi[g])
           atomicAdd(&Lg[tri(gi[h], gi[g])], g0 * te[e] + g1 * te[NTE + e] + g2 * te[2 * NTE + e]);
       }
-    srow[0] = a.out + (((int64_t)0 * a.ncells + cell) * 3 + ln) * NRT;
-    srow[1] = a.out + (((int64_t)1 * a.ncells + cell) * 3 + ln) * NRT;
     double Lce[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int i = 0; i < NRT; ++i)
     {
-      const double c0 = srow[0][i], c1 = srow[1][i];
+      const double c0 = (i % 2 == 0) ? sv[0][i / 2].x : sv[0][i / 2].y;
+      const double c1 = (i % 2 == 0) ? sv[1][i / 2].x : sv[1][i / 2].y;
       const double w0 = c0 * J[1][0] - c1 * J[0][0], w1 = c0 * J[1][1] - c1 * J[0][1];
 #pragma unroll
       for (int j = 0; j < 3; ++j)
