@@ -570,6 +570,7 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
       return fail(EQLB_ERR_INVALID_ARGUMENT, "node %d belongs to no cell", i);
   }
   free_boundary(h);
+  h->t_masked = node_mask != nullptr;
 
   // bins by lanes per patch: P = smallest of {4,8,16,32,64} >= number of patch facets
   std::vector<int64_t> node_slot(m.nnodes, -1), node_patch(m.nnodes, -1);
@@ -898,7 +899,8 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
       return fail(EQLB_ERR_UNSUPPORTED,
                   "the tiled scatter is available for k <= 2 flux equilibration with the shuffle solver");
     eqlb::TileArgs ta{h->t_tiles, h->t_tile_cells, h->ntiles, h->tile_tc,
-                      ev_conf ? h->t_facet_owner : nullptr, h->ev_cell_dofs, h->ev_ndofs, m.nfacets};
+                      ev_conf ? h->t_facet_owner : nullptr, h->ev_cell_dofs, h->ev_ndofs, m.nfacets,
+                      h->t_masked ? 1 : 0};
     a.slot_cell = h->t_slot_cell;
     a.slot_info = h->t_slot_info;
     a.pn = h->t_pn;

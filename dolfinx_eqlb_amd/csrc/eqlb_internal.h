@@ -107,6 +107,7 @@ struct TileArgs
   const int32_t* cell_dofs;   // caller's dofmap or nullptr (default numbering)
   int64_t ndofs;
   int32_t nfacets;
+  int32_t zero_slots; // 1: some (cell, vertex) rows are never written (node_mask): zero the LDS slots
 };
 
 struct BuildArgs
@@ -229,6 +230,7 @@ struct eqlb_se
   int32_t *t_tile_cells = nullptr, *t_slot_cell = nullptr, *t_facet_owner = nullptr;
   uint32_t* t_slot_info = nullptr;
   uint8_t *t_pn = nullptr, *t_pflag = nullptr;
+  bool t_masked = false;            // set_boundary got a node_mask (tiles then hold unwritten rows)
   double* slots = nullptr;          // [nrhs][ncells][3][nrt]
   int32_t* status = nullptr;
   // staging for host-memory calls
