@@ -241,6 +241,13 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin, eqlb::BuildArgs
     }
     for (int b = 0; b < eqlb::MAX_BINS; ++b)
     {
+      // full interior patches (as many cells as lanes, no boundary facet) first: their wave-blocks
+      // run the specialised body of the kernel
+      const int Pb = eqlb::BIN_P[b];
+      const auto mid = std::stable_partition(blist[b].begin(), blist[b].end(), [&](int32_t nd) {
+        return m.h_node_ncells[nd] == Pb && m.h_node_nfcts[nd] == Pb;
+      });
+      tiles[t].nfull[b] = (int32_t)(mid - blist[b].begin());
       tiles[t].slot_start[b] = (int32_t)slotctr;
       tiles[t].patch_start[b] = (int32_t)inst_node.size();
       tiles[t].npatch[b] = (int32_t)blist[b].size();

@@ -95,6 +95,7 @@ struct TileDesc
   int32_t slot_start[MAX_BINS]; // first lane slot of the tile's patches of bin b (multiple of 64)
   int32_t patch_start[MAX_BINS];
   int32_t npatch[MAX_BINS];
+  int32_t nfull[MAX_BINS]; // leading patches of the bin that are interior with exactly P cells
 };
 
 struct TileArgs

@@ -85,7 +85,7 @@ int fill_tables_host(int k, int deg, std::vector<double>& out)
 // DOFs and the zero-order facet moments explicitly (conforming particular solution: no jump data),
 // what remains is the SPD minimisation of || sigma - hat_a G || over the patch-wise H(div=0) space,
 // i.e. the same matrix with the additional load (phi_h, hat_a G) (tensors HG, WG).
-template <int K, int DEG, int P, int SOLVER, int SCATTER, int BLOCK, int MODE = 0>
+template <int K, int DEG, int P, int SOLVER, int SCATTER, int BLOCK, int MODE = 0, bool FULL = false>
 __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t block_id, double* lds,
                                               const bool tables_staged = false,
                                               const int64_t lane_index = -1, double* tile_slots = nullptr)
@@ -143,7 +143,16 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
     flag0 = a.pflag[patch];
     flag = a.pflag[(int64_t)r * a.npatch_total + patch];
   }
-  const bool active = cell_raw >= 0;
+  // FULL: the caller guarantees that every patch of this wave-block is interior with exactly P
+  // cells (tiled launch, leading patches of a bin): the patch shape becomes a compile-time constant
+  // and the masks for missing neighbours, boundary conditions and idle lanes fold away
+  if constexpr (FULL)
+  {
+    n = P;
+    flag0 = (uint8_t)PFLAG_INTERIOR;
+    flag = (uint8_t)0;
+  }
+  const bool active = FULL ? true : (cell_raw >= 0);
   const int32_t cell = active ? cell_raw : 0;
   const int fm = (info >> INFO_FM_SHIFT) & 3, fp = (info >> INFO_FP_SHIFT) & 3;
   const int ln = (info >> INFO_LN_SHIFT) & 3;
@@ -1435,7 +1444,7 @@ int launch_ev_patch_fused(int k, const SeArgs& a, const FusedBins& fb, hipStream
 // One workgroup (8 waves) per tile of TC owned cells.  It solves every patch that touches an owned
 // cell (patches on the tile rim are solved by each tile they touch), writes the (cell, vertex) rows
 // of its OWN cells into LDS - every row exactly once, no atomics - and finally adds
-// row(v0) + row(v1) + row(v2) in fixed order to flux_hdiv: bitwise reproducible like the slot path.
+// row(v0) + row(v1) + row(v2) in fixed order to flux_hdiv: bitwise reproducible from run to run.
 #ifndef EQLB_XCD_REMAP
 #define EQLB_XCD_REMAP 1
 #endif
@@ -1562,8 +1571,16 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
     a.npatch = np;                                                                                  \
     a.slot_offset = td.slot_start[B];                                                               \
     a.patch_offset = td.patch_start[B];                                                             \
+    /* complete wave-blocks of full patches (RT_1: the body is too small for the second instance to pay) */ \
+    constexpr bool SPEC = PP <= 8 && K >= 2;                                                        \
+    const int nwb_full = SPEC ? ((td.nfull[B] * PP) >> 6) : 0;                                      \
     for (; u < nwb; u += NW)                                                                        \
-      se_patch_body<K, DEG, PP, EQLB_TILE_SOLVER, 2, 64, MODE>(a, 0, lds, true, (int64_t)u * 64 + lane, sSlots); \
+    {                                                                                               \
+      if (u < nwb_full)                                                                             \
+        se_patch_body<K, DEG, PP, EQLB_TILE_SOLVER, 2, 64, MODE, SPEC>(a, 0, lds, true, (int64_t)u * 64 + lane, sSlots); \
+      else                                                                                          \
+        se_patch_body<K, DEG, PP, EQLB_TILE_SOLVER, 2, 64, MODE>(a, 0, lds, true, (int64_t)u * 64 + lane, sSlots); \
+    }                                                                                               \
     u -= nwb;                                                                                       \
   }
 #ifndef EQLB_EXP_NOBODY

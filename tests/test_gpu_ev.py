@@ -143,8 +143,9 @@ def test_ev_tiled_is_bitwise_the_slot_path(oracle_mod, k):
         out[sc] = eq.equilibrate_host(G, f)
         eq.set_option("output", 1)
         out[sc, "broken"] = eq.equilibrate_host(G, f)
-    assert np.array_equal(out[0], out[2])
-    assert np.array_equal(out[0, "broken"], out[2, "broken"])
+    # (to rounding: full interior patches run a specialised instance of the body on the tiled launch)
+    assert np.abs(out[0] - out[2]).max() <= 1e-13 * np.abs(out[0]).max()
+    assert np.abs(out[0, "broken"] - out[2, "broken"]).max() <= 1e-13 * np.abs(out[0, "broken"]).max()
     ref = oracle_mod.ev_reconstruct(mesh, k, ft, G, f, cd, nd)
     assert _close(out[2], ref)
     # custom dofmap on the tiled path

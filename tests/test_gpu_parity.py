@@ -194,11 +194,15 @@ def test_sampled_patches_against_oracle_at_scale(cpp, oracle_mod):
 @pytest.mark.parametrize("bc", ["dirichlet", "neumann_lt"])
 def test_tiled_scatter_is_bitwise_the_slot_path(cpp, oracle_mod, k, bc):
     """EQLB_SCATTER_TILED (one workgroup per tile of cells, vertex rows summed in LDS in fixed
-    order): same bits as slots + reduction; 20x20 crossed squares = several tiles with rims."""
+    order): the slot path to rounding (full interior patches run a specialised instance of the
+    patch body on the tiled launch: same arithmetic, other fused multiply-adds) and bitwise
+    reproducible from run to run; 20x20 crossed squares = several tiles with rims."""
     mesh, ft, G, f = make_case(20, k, bc)
     a, _ = _gpu(cpp, mesh, k, ft, G, f, scatter=0)
     b, eq = _gpu(cpp, mesh, k, ft, G, f, scatter=2)
-    assert np.array_equal(a, b)
+    assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max()
+    b2, _ = _gpu(cpp, mesh, k, ft, G, f, scatter=2)
+    assert np.array_equal(b, b2)
     ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f)
     assert np.abs(b - ref).max() <= RTOL * np.abs(ref).max()
     # accumulation into an existing vector
@@ -220,11 +224,11 @@ def test_tiled_scatter_multirhs_and_node_mask(cpp):
     f = np.stack([d[1] for d in data])
     a, _ = _gpu(cpp, mesh, k, ft, G, f, scatter=0)
     b, _ = _gpu(cpp, mesh, k, ft, G, f, scatter=2)
-    assert np.array_equal(a, b)
+    assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max()
     mask = (mesh.x[:, 0] < 0.5).astype(np.uint8)
     am, _ = _gpu(cpp, mesh, k, ft, G, f, scatter=0, node_mask=mask)
     bm, _ = _gpu(cpp, mesh, k, ft, G, f, scatter=2, node_mask=mask)
-    assert np.array_equal(am, bm)
+    assert np.abs(am - bm).max() <= 1e-13 * np.abs(a).max()
 
 
 @pytest.mark.parametrize("k,deg", [(2, 0), (3, 1), (3, 0)])
