@@ -693,8 +693,8 @@ struct WsLean
   static constexpr int DM = Z::DIMMAX;     // 1 + P  (<= 9)
   static constexpr int TRI = DM * (DM + 1) / 2;
   static constexpr int NPM = P + 2, DCM = NPM + 1, LDB = NPM;
-  // per patch: L (packed lower) | 1/L_ii | Yb [DM][LDB] | Mv [NPM] | R [DCM] | W [2][DM]
-  static constexpr int OFF_D = TRI, OFF_Y = OFF_D + DM, OFF_M = OFF_Y + DM * LDB, OFF_R = OFF_M + NPM,
+  // per patch: L (packed lower) | 1/L_ii | Yb [2][DM][LDB] | Mv [NPM] | R [DCM] | W [2][DM]
+  static constexpr int OFF_D = TRI, OFF_Y = OFF_D + DM, OFF_M = OFF_Y + 2 * DM * LDB, OFF_R = OFF_M + NPM,
                        OFF_W = OFF_R + DCM, GROUP = OFF_W + 2 * DM;
   static constexpr int NTAB = Z::NTET + Z::NVT + Z::NVQT;
   static constexpr int BLOCK = 256;
@@ -845,6 +845,17 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
       atomicAdd(&Rg[pj[j]], Lce[j]);
       atomicAdd(&Mv[pj[j]], Ce);
     }
+    // B_k of this lane's cell into Yb[k]: Be[h][j], k = 0: int (Phi_h)_y psi_j, k = 1: -int (Phi_h)_x psi_j
+    const double* vq = sVQ + ci * 2 * NH * 3;
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+      {
+        const double v0 = vq[h * 3 + j], v1 = vq[(NH + h) * 3 + j];
+        atomicAdd(&Yb[gi[h] * LDB + pj[j]], J[1][0] * v0 + J[1][1] * v1);
+        atomicAdd(&Yb[DM * LDB + gi[h] * LDB + pj[j]], -(J[0][0] * v0 + J[0][1] * v1));
+      }
   }
   wave_sync();
 
@@ -886,50 +897,38 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
   wave_sync();
 
   // B_k of this lane's cell: Be[h][j], k = 0: int (Phi_h)_y psi_j, k = 1: -int (Phi_h)_x psi_j
-  // Columns of this lane: point 0 (the patch node; the same in every lane) and ring point sub + 1.
-  // B_k of this lane's cell: Be[h][j], k = 0: int (Phi_h)_y psi_j, k = 1: -int (Phi_h)_x psi_j
+  // Columns of this lane: point 0 (the patch node; the same in every lane) and ring point sub + 1,
+  // of Y_0 and Y_1 together (one sweep over the factor for the four vectors): y = L^-1 b
   const bool own_pt = sub + 1 < npnt; // the lane owns ring point sub + 1
-  auto form_Y = [&](int k, double (&y0)[DM], double (&y1)[DM]) {
-    // assemble B_k into Yb, then the two columns: y = L^-1 b
-    for (int e = sub; e < DM * LDB; e += P)
-      Yb[e] = 0.0;
-    wave_sync();
-    if (active)
-    {
-      const double* vq = sVQ + ci * 2 * NH * 3;
+  double ys0[2][DM], ys1[2][DM]; // kept for the back substitution
 #pragma unroll
-      for (int h = 0; h < NH; ++h)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-        {
-          const double v0 = vq[h * 3 + j], v1 = vq[(NH + h) * 3 + j];
-          const double b = (k == 0) ? (J[1][0] * v0 + J[1][1] * v1) : -(J[0][0] * v0 + J[0][1] * v1);
-          atomicAdd(&Yb[gi[h] * LDB + pj[j]], b);
-        }
-    }
-    wave_sync();
+  for (int k = 0; k < 2; ++k)
 #pragma unroll
     for (int i = 0; i < DM; ++i)
     {
-      y0[i] = Yb[i * LDB];
-      y1[i] = own_pt ? Yb[i * LDB + sub + 1] : 0.0;
+      ys0[k][i] = Yb[k * DM * LDB + i * LDB];
+      ys1[k][i] = own_pt ? Yb[k * DM * LDB + i * LDB + sub + 1] : 0.0;
     }
 #pragma unroll
-    for (int i = 0; i < DM; ++i)
+  for (int i = 0; i < DM; ++i)
+  {
+    double t00 = ys0[0][i], t01 = ys1[0][i], t10 = ys0[1][i], t11 = ys1[1][i];
+#pragma unroll
+    for (int q = 0; q < i; ++q)
     {
-      double t0 = y0[i], t1 = y1[i];
-#pragma unroll
-      for (int q = 0; q < i; ++q)
-      {
-        const double l = Lg[tri(i, q)];
-        t0 -= l * y0[q];
-        t1 -= l * y1[q];
-      }
-      const double d = Dg[i];
-      y0[i] = t0 * d; // rows >= dim of the factor are identity rows, the data there is zero
-      y1[i] = t1 * d;
+      const double l = Lg[tri(i, q)];
+      t00 -= l * ys0[0][q];
+      t01 -= l * ys1[0][q];
+      t10 -= l * ys0[1][q];
+      t11 -= l * ys1[1][q];
     }
-  };
+    const double d = Dg[i];
+    asm volatile("" : "+v"(t00), "+v"(t01), "+v"(t10), "+v"(t11));
+    ys0[0][i] = t00 * d; // rows >= dim of the factor are identity rows, the data there is zero
+    ys1[0][i] = t01 * d;
+    ys0[1][i] = t10 * d;
+    ys1[1][i] = t11 * d;
+  }
 
   // ---- Schur system in registers: row of ring point sub + 1 in its lane, row of point 0 in every
   // lane.  S = sum_k Y_k^T Y_k is symmetric positive (semi-)definite, so no pivoting is needed
@@ -944,42 +943,38 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
 #pragma unroll
   for (int j = 0; j <= NPT; ++j)
     rv[j] = rn[j] = 0.0;
-  double ys0[2][DM], ys1[2][DM]; // the lane's columns of Y_0, Y_1 (kept for the back substitution)
+  // publish the substituted columns, then S[r][c] = sum_k y_r . y_c for the lane's two rows
 #pragma unroll
   for (int k = 0; k < 2; ++k)
-  {
-    double(&y0)[DM] = ys0[k];
-    double(&y1)[DM] = ys1[k];
-    form_Y(k, y0, y1);
-    // publish the substituted columns, then S[r][c] += y_r . y_c for the lane's two rows
 #pragma unroll
     for (int i = 0; i < DM; ++i)
     {
       if (sub == 0)
-        Yb[i * LDB] = y0[i];
+        Yb[k * DM * LDB + i * LDB] = ys0[k][i];
       if (own_pt)
-        Yb[i * LDB + sub + 1] = y1[i];
+        Yb[k * DM * LDB + i * LDB + sub + 1] = ys1[k][i];
     }
-    wave_sync();
+  wave_sync();
 #pragma unroll
-    for (int c = 0; c < NPT; ++c)
-    {
-      double t0 = 0.0, t1 = 0.0;
+  for (int c = 0; c < NPT; ++c)
+  {
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
       for (int i = 0; i < DM; ++i)
       {
-        const double yc = Yb[i * LDB + c]; // columns >= npnt are zero
-        t0 += y0[i] * yc;
-        t1 += y1[i] * yc;
+        const double yc = Yb[k * DM * LDB + i * LDB + c]; // columns >= npnt are zero
+        t0 += ys0[k][i] * yc;
+        t1 += ys1[k][i] * yc;
       }
-      // pin the two dot products here: otherwise the compiler sinks the FMAs of all columns below
-      // the LDS reads of all columns (180 live VGPRs, spilled)
-      asm volatile("" : "+v"(t0), "+v"(t1));
-      rn[c] += t0;
-      rv[c] += t1;
-    }
-    wave_sync();
+    // pin the two dot products here: otherwise the compiler sinks the FMAs of all columns below
+    // the LDS reads of all columns (live VGPRs, spilled)
+    asm volatile("" : "+v"(t0), "+v"(t1));
+    rn[c] = t0;
+    rv[c] = t1;
   }
+  wave_sync();
   double gam[NPT], g_own = 0.0;
   int sing = 0;
   {
