@@ -152,7 +152,10 @@ struct Sizes
   static constexpr int TRI = DIMMAX * (DIMMAX + 1) / 2;
   static constexpr int LDS_GROUP = TRI + DIMMAX; // doubles per patch for SOLVER 0
   // device table buffer: S | F | H | D | TE | WQ ; the kernel stages everything behind S in LDS
-  static constexpr int NS = 3 * NRT * NRT, NF = 9 * ND * K, NHT = 3 * ND * NQ, NDT = 6 * ND * NQ;
+  // rows of H padded to an even number of doubles: with it every segment and every row of the k = 2
+  // tensors starts on a 16-byte boundary in LDS (ds_read_b128 instead of the half-rate ds_read2_b64)
+  static constexpr int HROW = ND * NQ + ((ND * NQ) & 1);
+  static constexpr int NS = 3 * NRT * NRT, NF = 9 * ND * K, NHT = 3 * HROW, NDT = 6 * ND * NQ;
   static constexpr int NTET = NCOMBO * 3 * NTE, NWQT = NCOMBO * 3 * NH * NCOL;
   static constexpr int NHB = 9 * K * K;                           // flux-BC tensor HB
   static constexpr int NTAB = NF + NHT + NDT + NTET + NWQT + NHB;

@@ -29,7 +29,8 @@ size_t table_doubles(int k, int deg)
   const int nrt = nrt_of(k), nd = nd_of(deg), nq = nq_of(k);
   const int kb = k - 1, nadd = (k - 1) * (k - 2) / 2, ndiv = k * (k + 1) / 2 - 1;
   const int nh = 1 + 2 * kb + nadd, ncol = 2 * k + ndiv;
-  return (size_t)3 * nrt * nrt + (size_t)9 * nd * k + (size_t)3 * nd * nq + (size_t)6 * nd * nq
+  const int hrow = nd * nq + ((nd * nq) & 1); // Sizes::HROW
+  return (size_t)3 * nrt * nrt + (size_t)9 * nd * k + (size_t)3 * hrow + (size_t)6 * nd * nq
          + (size_t)NCOMBO * 3 * (nh * (nh + 1) / 2) + (size_t)NCOMBO * 3 * nh * ncol
          + (size_t)9 * k * k + (size_t)3 * nrt * 2 + (size_t)NCOMBO * 2 * nh * 3
          + (size_t)nd * nq + (size_t)NCOMBO * nh * nd * 2;
@@ -42,7 +43,13 @@ static void fill_tables_t(std::vector<double>& out)
   out.clear();
   out.insert(out.end(), R::S, R::S + R::S_SIZE);
   out.insert(out.end(), R::F, R::F + R::F_SIZE);
-  out.insert(out.end(), R::H, R::H + R::H_SIZE);
+  static_assert(R::H_SIZE % 3 == 0, "H holds one row per local vertex");
+  for (int n = 0; n < 3; ++n) // rows padded to an even length (Sizes::HROW)
+  {
+    out.insert(out.end(), R::H + n * (R::H_SIZE / 3), R::H + (n + 1) * (R::H_SIZE / 3));
+    if ((R::H_SIZE / 3) & 1)
+      out.push_back(0.0);
+  }
   out.insert(out.end(), R::D, R::D + R::D_SIZE);
   out.insert(out.end(), R::TE, R::TE + R::TE_SIZE);
   out.insert(out.end(), R::WQ, R::WQ + R::WQ_SIZE);
@@ -85,6 +92,30 @@ int fill_tables_host(int k, int deg, std::vector<double>& out)
 // DOFs and the zero-order facet moments explicitly (conforming particular solution: no jump data),
 // what remains is the SPD minimisation of || sigma - hat_a G || over the patch-wise H(div=0) space,
 // i.e. the same matrix with the additional load (phi_h, hat_a G) (tensors HG, WG).
+template <bool AL>
+__device__ __forceinline__ const double* row16(const double* p)
+{
+  if constexpr (AL)
+    return static_cast<const double*>(__builtin_assume_aligned(p, 16));
+  else
+    return p;
+}
+
+// N doubles (N even) from a 16-byte aligned LDS row: 128-bit reads
+template <int N>
+__device__ __forceinline__ void ldrow16(const double* p, double (&r)[N])
+{
+  static_assert(N % 2 == 0, "row length");
+  const double2* q = reinterpret_cast<const double2*>(p);
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i)
+  {
+    const double2 v = q[i];
+    r[2 * i] = v.x;
+    r[2 * i + 1] = v.y;
+  }
+}
+
 template <int K, int DEG, int P, int SOLVER, int SCATTER, int BLOCK, int MODE = 0, bool FULL = false>
 __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t block_id, double* lds,
                                               const bool tables_staged = false,
@@ -94,6 +125,13 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   constexpr int KB = Z::KB, NADD = Z::NADD, NDIV = Z::NDIV, NRT = Z::NRT, ND = Z::ND, NQ = Z::NQ;
   constexpr int NCOL = Z::NCOL, NH = Z::NH, NTE = Z::NTE;
 
+  // RT_2 with P1 data: every segment and every row used below has an even number of doubles, the
+  // rows start on 16-byte boundaries (the dynamic LDS segment does): 128-bit LDS reads
+  constexpr bool AL = K == 2 && DEG == 1;
+  static_assert(!AL || (Z::NF % 2 == 0 && Z::NHT % 2 == 0 && Z::NDT % 2 == 0 && Z::NTET % 2 == 0
+                        && Z::NWQT % 2 == 0 && (ND * K) % 2 == 0 && Z::HROW % 2 == 0
+                        && (3 * NTE) % 2 == 0 && (3 * NH * NCOL) % 2 == 0),
+                "table rows are not 16-byte aligned");
   double* sF = lds;             // [3][3][ND][K]
   double* sH = sF + Z::NF;      // [3][ND][NQ]
   double* sD = sH + Z::NHT;     // [3][ND][2][NQ]
@@ -237,7 +275,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
           LeG[h] = 0.0;
         if (active)
         {
-          const double* tH = sH + ln * ND * NQ;
+          const double* tH = sH + ln * Z::HROW;
           const double* wg = sWG + ci * NH * ND * 2;
           // reference gradient of the hat function of the patch node
           const double dh0 = (ln == 0) ? -1.0 : ((ln == 1) ? 1.0 : 0.0);
@@ -261,9 +299,9 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       }
       else if (active)
       {
-        const double* tF_m = sF + (fm * 3 + ln) * ND * K;
-        const double* tF_p = sF + (fp * 3 + ln) * ND * K;
-        const double* tH = sH + ln * ND * NQ;
+        const double* tF_m = row16<AL>(sF + (fm * 3 + ln) * ND * K);
+        const double* tF_p = row16<AL>(sF + (fp * 3 + ln) * ND * K);
+        const double* tH = row16<AL>(sH + ln * Z::HROW);
         const double* tD = sD + ln * ND * 2 * NQ;
         double fdv[ND], dvg = 0.0;
         (void)fdv;
@@ -278,11 +316,26 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
           const double gh0 = a00 * g2.x + a01 * g2.y; // (adj G_i)_X
           const double gh1 = a10 * g2.x + a11 * g2.y;
           const double fd = detJ * fv;
-#pragma unroll
-          for (int j = 0; j < K; ++j)
+          if constexpr (AL)
           {
-            gm[j] += tF_m[i * K + j] * gnm;
-            gpv[j] += tF_p[i * K + j] * gnp;
+            double rm[K], rp[K];
+            ldrow16<K>(tF_m + i * K, rm);
+            ldrow16<K>(tF_p + i * K, rp);
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+            {
+              gm[j] += rm[j] * gnm;
+              gpv[j] += rp[j] * gnp;
+            }
+          }
+          else
+          {
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+            {
+              gm[j] += tF_m[i * K + j] * gnm;
+              gpv[j] += tF_p[i * K + j] * gnp;
+            }
           }
           if constexpr (DEG == 1)
           {
@@ -305,11 +358,20 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         }
         if constexpr (DEG == 1)
         {
+          double rH[Z::HROW];
+          if constexpr (AL)
+            ldrow16<Z::HROW>(tH, rH);
+          else
+          {
+#pragma unroll
+            for (int e = 0; e < ND * NQ; ++e)
+              rH[e] = tH[e];
+          }
 #pragma unroll
           for (int i = 0; i < ND; ++i)
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
-              Rq[q] += (fdv[i] - dvg) * tH[i * NQ + q];
+              Rq[q] += (fdv[i] - dvg) * rH[i * NQ + q];
         }
 #pragma unroll
         for (int j = 0; j < K; ++j)
@@ -472,17 +534,35 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       const double ia = active ? rcp_d(fabs(detJ)) : 0.0;
       const double g0 = (J00 * J00 + J10 * J10) * ia, g1 = (J00 * J01 + J10 * J11) * ia,
                    g2 = (J01 * J01 + J11 * J11) * ia;
-      const double* te = sTE + ci * 3 * NTE;
+      const double* te = row16<AL>(sTE + ci * 3 * NTE);
+      if constexpr (AL)
+      {
+        double rte[3 * NTE];
+        ldrow16<3 * NTE>(te, rte);
 #pragma unroll
-      for (int h = 0; h < NH; ++h)
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int g = 0; g <= h; ++g)
-        {
-          const int e = h * (h + 1) / 2 + g;
-          const double v = g0 * te[e] + g1 * te[NTE + e] + g2 * te[2 * NTE + e];
-          Te[h][g] = v;
-          Te[g][h] = v;
-        }
+          for (int g = 0; g <= h; ++g)
+          {
+            const int e = h * (h + 1) / 2 + g;
+            const double v = g0 * rte[e] + g1 * rte[NTE + e] + g2 * rte[2 * NTE + e];
+            Te[h][g] = v;
+            Te[g][h] = v;
+          }
+      }
+      else
+      {
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+          for (int g = 0; g <= h; ++g)
+          {
+            const int e = h * (h + 1) / 2 + g;
+            const double v = g0 * te[e] + g1 * te[NTE + e] + g2 * te[2 * NTE + e];
+            Te[h][g] = v;
+            Te[g][h] = v;
+          }
+      }
       double full[NCOL];
 #pragma unroll
       for (int j = 0; j < K; ++j)
@@ -493,17 +573,34 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 #pragma unroll
       for (int q = 0; q < NDIV; ++q)
         full[2 * K + q] = sgn * Rq[1 + q];
-      const double* wq = sWQ + ci * 3 * NH * NCOL;
+      const double* wq = row16<AL>(sWQ + ci * 3 * NH * NCOL);
 #pragma unroll
       for (int h = 0; h < NH; ++h)
       {
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int c = 0; c < NCOL; ++c)
+        if constexpr (AL)
         {
-          s0 += wq[h * NCOL + c] * full[c];
-          s1 += wq[(NH + h) * NCOL + c] * full[c];
-          s2 += wq[(2 * NH + h) * NCOL + c] * full[c];
+          double w0[NCOL], w1[NCOL], w2[NCOL];
+          ldrow16<NCOL>(wq + h * NCOL, w0);
+          ldrow16<NCOL>(wq + (NH + h) * NCOL, w1);
+          ldrow16<NCOL>(wq + (2 * NH + h) * NCOL, w2);
+#pragma unroll
+          for (int c = 0; c < NCOL; ++c)
+          {
+            s0 += w0[c] * full[c];
+            s1 += w1[c] * full[c];
+            s2 += w2[c] * full[c];
+          }
+        }
+        else
+        {
+#pragma unroll
+          for (int c = 0; c < NCOL; ++c)
+          {
+            s0 += wq[h * NCOL + c] * full[c];
+            s1 += wq[(NH + h) * NCOL + c] * full[c];
+            s2 += wq[(2 * NH + h) * NCOL + c] * full[c];
+          }
         }
         Le[h] = -(g0 * s0 + g1 * s1 + g2 * s2);
         if constexpr (MODE == 1)
@@ -1324,7 +1421,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 template <int K, int DEG, int P, int SOLVER, int SCATTER>
 __global__ void __launch_bounds__((Sizes<K, DEG, P>::block_of(SOLVER))) k_se_patch(const SeArgs a)
 {
-  extern __shared__ double lds[];
+  extern __shared__ __align__(16) double lds[];
   se_patch_body<K, DEG, P, SOLVER, SCATTER, Sizes<K, DEG, P>::block_of(SOLVER)>(a, blockIdx.x, lds);
 }
 
@@ -1343,7 +1440,7 @@ __global__ void __launch_bounds__(256, (K <= 2 ? EQLB_FUSED_WAVES : 1)) k_se_pat
   // the reference tensors in LDS once and then strides over the 256-lane work blocks of all bins;
   // its waves drift apart (no block barrier in the loop), so gathers of one wave overlap the
   // arithmetic of the others.
-  extern __shared__ double lds[];
+  extern __shared__ __align__(16) double lds[];
   using Z = Sizes<K, DEG, 8>;
   for (int i = threadIdx.x; i < Z::NTAB; i += 256)
     lds[i] = a0.tables[Z::NS + i];
@@ -1386,7 +1483,7 @@ __global__ void __launch_bounds__(256, (K <= 2 ? EQLB_FUSED_WAVES : 1)) k_se_pat
 template <int K, int DEG>
 __global__ void __launch_bounds__(256, (K <= 2 ? 2 : 1)) k_ev_patch_fused(const SeArgs a0, const FusedBins fb)
 {
-  extern __shared__ double lds[];
+  extern __shared__ __align__(16) double lds[];
   const int64_t bid = blockIdx.x;
   int b = 0;
 #pragma unroll
@@ -1533,7 +1630,7 @@ template <int K, int DEG, int MODE>
 __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patch_tiled(const SeArgs a0, const TileArgs ta)
 {
   constexpr int TILE_THREADS = tile_threads_c(K);
-  extern __shared__ double lds[];
+  extern __shared__ __align__(16) double lds[];
   using Z = Sizes<K, DEG, 8>;
   constexpr int NRT = Z::NRT;
   constexpr int TC = tile_cells_c(K);
