@@ -162,7 +162,7 @@ struct Sizes
   static constexpr int NVT = 3 * NRT * 2, NVQT = NCOMBO * 2 * NH * 3; // weak symmetry: V, VQ (behind HB)
   static constexpr int OFF_TE = NS + NF + NHT + NDT, OFF_V = OFF_TE + NTET + NWQT + NHB, OFF_VQ = OFF_V + NVT;
   // constrained-minimisation (EV) mode: HG | WG behind VQ, staged in LDS behind HB
-  static constexpr int NHG = ND * NQ, NWG = NCOMBO * NH * ND * 2, NEV = NHG + NWG;
+  static constexpr int NHG = HROW, NWG = NCOMBO * NH * ND * 2, NEV = NHG + NWG; // HG padded like a row of H
   static constexpr int OFF_HG = OFF_VQ + NVQT;
   // workgroup size: as many waves as fit a 64 KiB LDS budget for the dense tiles (at least one)
   static constexpr int lds_doubles(int block, int solver, int mode = 0)

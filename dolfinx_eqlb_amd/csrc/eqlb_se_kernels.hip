@@ -33,7 +33,7 @@ size_t table_doubles(int k, int deg)
   return (size_t)3 * nrt * nrt + (size_t)9 * nd * k + (size_t)3 * hrow + (size_t)6 * nd * nq
          + (size_t)NCOMBO * 3 * (nh * (nh + 1) / 2) + (size_t)NCOMBO * 3 * nh * ncol
          + (size_t)9 * k * k + (size_t)3 * nrt * 2 + (size_t)NCOMBO * 2 * nh * 3
-         + (size_t)nd * nq + (size_t)NCOMBO * nh * nd * 2;
+         + (size_t)hrow + (size_t)NCOMBO * nh * nd * 2;
 }
 
 template <int K, int DEG>
@@ -57,6 +57,8 @@ static void fill_tables_t(std::vector<double>& out)
   out.insert(out.end(), R::V, R::V + R::V_SIZE);
   out.insert(out.end(), R::VQ, R::VQ + R::VQ_SIZE);
   out.insert(out.end(), R::HG, R::HG + R::HG_SIZE);
+  if (R::HG_SIZE & 1) // Sizes::NHG
+    out.push_back(0.0);
   out.insert(out.end(), R::WG, R::WG + R::WG_SIZE);
 }
 
@@ -130,7 +132,8 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   constexpr bool AL = K == 2 && DEG == 1;
   static_assert(!AL || (Z::NF % 2 == 0 && Z::NHT % 2 == 0 && Z::NDT % 2 == 0 && Z::NTET % 2 == 0
                         && Z::NWQT % 2 == 0 && (ND * K) % 2 == 0 && Z::HROW % 2 == 0
-                        && (3 * NTE) % 2 == 0 && (3 * NH * NCOL) % 2 == 0),
+                        && (3 * NTE) % 2 == 0 && (3 * NH * NCOL) % 2 == 0 && Z::NHB % 2 == 0
+                        && Z::NHG % 2 == 0),
                 "table rows are not 16-byte aligned");
   double* sF = lds;             // [3][3][ND][K]
   double* sH = sF + Z::NF;      // [3][ND][NQ]
@@ -275,8 +278,9 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
           LeG[h] = 0.0;
         if (active)
         {
-          const double* tH = sH + ln * Z::HROW;
-          const double* wg = sWG + ci * NH * ND * 2;
+          const double* tH = row16<AL>(sH + ln * Z::HROW);
+          const double* wg = row16<AL>(sWG + ci * NH * ND * 2);
+
           // reference gradient of the hat function of the patch node
           const double dh0 = (ln == 0) ? -1.0 : ((ln == 1) ? 1.0 : 0.0);
           const double dh1 = (ln == 0) ? -1.0 : ((ln == 2) ? 1.0 : 0.0);
@@ -293,7 +297,15 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
               Rq[q] += fd * tH[i * NQ + q] + gg * sHG[i * NQ + q];
 #pragma unroll
             for (int h = 0; h < NH; ++h)
-              LeG[h] += wg[(h * ND + i) * 2] * jt0 + wg[(h * ND + i) * 2 + 1] * jt1;
+            {
+              if constexpr (AL)
+              {
+                const double2 w2 = reinterpret_cast<const double2*>(wg)[h * ND + i];
+                LeG[h] += w2.x * jt0 + w2.y * jt1;
+              }
+              else
+                LeG[h] += wg[(h * ND + i) * 2] * jt0 + wg[(h * ND + i) * 2 + 1] * jt1;
+            }
           }
         }
       }
@@ -537,15 +549,22 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       const double* te = row16<AL>(sTE + ci * 3 * NTE);
       if constexpr (AL)
       {
-        double rte[3 * NTE];
-        ldrow16<3 * NTE>(te, rte);
+        double tev[NTE]; // two entries per step: one 128-bit read from each metric row
+#pragma unroll
+        for (int e2 = 0; e2 < NTE / 2; ++e2)
+        {
+          const double2 t0 = reinterpret_cast<const double2*>(te)[e2];
+          const double2 t1 = reinterpret_cast<const double2*>(te + NTE)[e2];
+          const double2 t2 = reinterpret_cast<const double2*>(te + 2 * NTE)[e2];
+          tev[2 * e2] = g0 * t0.x + g1 * t1.x + g2 * t2.x;
+          tev[2 * e2 + 1] = g0 * t0.y + g1 * t1.y + g2 * t2.y;
+        }
 #pragma unroll
         for (int h = 0; h < NH; ++h)
 #pragma unroll
           for (int g = 0; g <= h; ++g)
           {
-            const int e = h * (h + 1) / 2 + g;
-            const double v = g0 * rte[e] + g1 * rte[NTE + e] + g2 * rte[2 * NTE + e];
+            const double v = tev[h * (h + 1) / 2 + g];
             Te[h][g] = v;
             Te[g][h] = v;
           }
@@ -580,16 +599,15 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
         if constexpr (AL)
         {
-          double w0[NCOL], w1[NCOL], w2[NCOL];
-          ldrow16<NCOL>(wq + h * NCOL, w0);
-          ldrow16<NCOL>(wq + (NH + h) * NCOL, w1);
-          ldrow16<NCOL>(wq + (2 * NH + h) * NCOL, w2);
 #pragma unroll
-          for (int c = 0; c < NCOL; ++c)
+          for (int c2 = 0; c2 < NCOL / 2; ++c2)
           {
-            s0 += w0[c] * full[c];
-            s1 += w1[c] * full[c];
-            s2 += w2[c] * full[c];
+            const double2 w0 = reinterpret_cast<const double2*>(wq + h * NCOL)[c2];
+            const double2 w1 = reinterpret_cast<const double2*>(wq + (NH + h) * NCOL)[c2];
+            const double2 w2 = reinterpret_cast<const double2*>(wq + (2 * NH + h) * NCOL)[c2];
+            s0 += w0.x * full[2 * c2] + w0.y * full[2 * c2 + 1];
+            s1 += w1.x * full[2 * c2] + w1.y * full[2 * c2 + 1];
+            s2 += w2.x * full[2 * c2] + w2.y * full[2 * c2 + 1];
           }
         }
         else
