@@ -13,7 +13,7 @@ for f in glob.glob("gpurun_out/pmc9/p*/**/*_counter_collection.csv", recursive=T
         if "k_se_patch_tiled" in row["Kernel_Name"]:
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 with open("gpurun_out/pmc9/summary.csv", "w") as fh:
-    fh.write("# r01 v9: PMC counters of k_se_patch_tiled<2,1,0> (mean per launch), rocprofv3 --pmc passes, bench.py --steps 3\ncounter,value\n")
+    fh.write("# PMC counters of k_se_patch_tiled<2,1,0> (mean per launch), rocprofv3 --pmc passes, bench.py --steps 3\ncounter,value\n")
     for k in sorted(acc):
         fh.write(f"{k},{sum(acc[k]) / len(acc[k]):.1f}\n")
 print(open("gpurun_out/pmc9/summary.csv").read())
