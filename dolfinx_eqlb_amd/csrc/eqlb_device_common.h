@@ -148,6 +148,8 @@ struct Sizes
   static constexpr int NCOL = 2 * K + NDIV;    // columns of the load tensor: mu_m, mu_p, div DOFs
   static constexpr int NH = 1 + 2 * KB + NADD; // local unknowns [d | um | up | ua]
   static constexpr int NTE = NH * (NH + 1) / 2;
+  // row strides of TE / WQ in the table buffer, padded to an even number of doubles (16-byte rows)
+  static constexpr int NTES = NTE + (NTE & 1), NCOLS = NCOL + (NCOL & 1);
   static constexpr int DIMMAX = 1 + KB * P + NADD * P;
   static constexpr int TRI = DIMMAX * (DIMMAX + 1) / 2;
   static constexpr int LDS_GROUP = TRI + DIMMAX; // doubles per patch for SOLVER 0
@@ -156,7 +158,7 @@ struct Sizes
   // tensors starts on a 16-byte boundary in LDS (ds_read_b128 instead of the half-rate ds_read2_b64)
   static constexpr int HROW = ND * NQ + ((ND * NQ) & 1);
   static constexpr int NS = 3 * NRT * NRT, NF = 9 * ND * K, NHT = 3 * HROW, NDT = 6 * ND * NQ;
-  static constexpr int NTET = NCOMBO * 3 * NTE, NWQT = NCOMBO * 3 * NH * NCOL;
+  static constexpr int NTET = NCOMBO * 3 * NTES, NWQT = NCOMBO * 3 * NH * NCOLS;
   static constexpr int NHB = 9 * K * K;                           // flux-BC tensor HB
   static constexpr int NTAB = NF + NHT + NDT + NTET + NWQT + NHB;
   static constexpr int NVT = 3 * NRT * 2, NVQT = NCOMBO * 2 * NH * 3; // weak symmetry: V, VQ (behind HB)

@@ -30,8 +30,9 @@ size_t table_doubles(int k, int deg)
   const int kb = k - 1, nadd = (k - 1) * (k - 2) / 2, ndiv = k * (k + 1) / 2 - 1;
   const int nh = 1 + 2 * kb + nadd, ncol = 2 * k + ndiv;
   const int hrow = nd * nq + ((nd * nq) & 1); // Sizes::HROW
+  const int nte = nh * (nh + 1) / 2;         // rows of TE / WQ padded like Sizes::NTES / NCOLS
   return (size_t)3 * nrt * nrt + (size_t)9 * nd * k + (size_t)3 * hrow + (size_t)6 * nd * nq
-         + (size_t)NCOMBO * 3 * (nh * (nh + 1) / 2) + (size_t)NCOMBO * 3 * nh * ncol
+         + (size_t)NCOMBO * 3 * (nte + (nte & 1)) + (size_t)NCOMBO * 3 * nh * (ncol + (ncol & 1))
          + (size_t)9 * k * k + (size_t)3 * nrt * 2 + (size_t)NCOMBO * 2 * nh * 3
          + (size_t)hrow + (size_t)NCOMBO * nh * nd * 2;
 }
@@ -51,8 +52,20 @@ static void fill_tables_t(std::vector<double>& out)
       out.push_back(0.0);
   }
   out.insert(out.end(), R::D, R::D + R::D_SIZE);
-  out.insert(out.end(), R::TE, R::TE + R::TE_SIZE);
-  out.insert(out.end(), R::WQ, R::WQ + R::WQ_SIZE);
+  {
+    using Z = Sizes<K, DEG, 8>;
+    static_assert(R::TE_SIZE == NCOMBO * 3 * Z::NTE && R::WQ_SIZE == NCOMBO * 3 * Z::NH * Z::NCOL, "tensor sizes");
+    for (int r = 0; r < NCOMBO * 3; ++r) // rows padded to Sizes::NTES
+    {
+      out.insert(out.end(), R::TE + r * Z::NTE, R::TE + (r + 1) * Z::NTE);
+      out.insert(out.end(), Z::NTES - Z::NTE, 0.0);
+    }
+    for (int r = 0; r < NCOMBO * 3 * Z::NH; ++r) // rows padded to Sizes::NCOLS
+    {
+      out.insert(out.end(), R::WQ + r * Z::NCOL, R::WQ + (r + 1) * Z::NCOL);
+      out.insert(out.end(), Z::NCOLS - Z::NCOL, 0.0);
+    }
+  }
   out.insert(out.end(), R::HB, R::HB + R::HB_SIZE);
   out.insert(out.end(), R::V, R::V + R::V_SIZE);
   out.insert(out.end(), R::VQ, R::VQ + R::VQ_SIZE);
@@ -132,7 +145,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   constexpr bool AL = K == 2 && DEG == 1;
   static_assert(!AL || (Z::NF % 2 == 0 && Z::NHT % 2 == 0 && Z::NDT % 2 == 0 && Z::NTET % 2 == 0
                         && Z::NWQT % 2 == 0 && (ND * K) % 2 == 0 && Z::HROW % 2 == 0
-                        && (3 * NTE) % 2 == 0 && (3 * NH * NCOL) % 2 == 0 && Z::NHB % 2 == 0
+                        && Z::NTES % 2 == 0 && Z::NCOLS % 2 == 0 && Z::NHB % 2 == 0
                         && Z::NHG % 2 == 0),
                 "table rows are not 16-byte aligned");
   double* sF = lds;             // [3][3][ND][K]
@@ -546,16 +559,17 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       const double ia = active ? rcp_d(fabs(detJ)) : 0.0;
       const double g0 = (J00 * J00 + J10 * J10) * ia, g1 = (J00 * J01 + J10 * J11) * ia,
                    g2 = (J01 * J01 + J11 * J11) * ia;
-      const double* te = row16<AL>(sTE + ci * 3 * NTE);
+      constexpr int NTES = Z::NTES, NCOLS = Z::NCOLS;
+      const double* te = row16<AL>(sTE + ci * 3 * NTES);
       if constexpr (AL)
       {
-        double tev[NTE]; // two entries per step: one 128-bit read from each metric row
+        double tev[NTES]; // two entries per step: one 128-bit read from each metric row
 #pragma unroll
-        for (int e2 = 0; e2 < NTE / 2; ++e2)
+        for (int e2 = 0; e2 < NTES / 2; ++e2)
         {
           const double2 t0 = reinterpret_cast<const double2*>(te)[e2];
-          const double2 t1 = reinterpret_cast<const double2*>(te + NTE)[e2];
-          const double2 t2 = reinterpret_cast<const double2*>(te + 2 * NTE)[e2];
+          const double2 t1 = reinterpret_cast<const double2*>(te + NTES)[e2];
+          const double2 t2 = reinterpret_cast<const double2*>(te + 2 * NTES)[e2];
           tev[2 * e2] = g0 * t0.x + g1 * t1.x + g2 * t2.x;
           tev[2 * e2 + 1] = g0 * t0.y + g1 * t1.y + g2 * t2.y;
         }
@@ -577,7 +591,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
           for (int g = 0; g <= h; ++g)
           {
             const int e = h * (h + 1) / 2 + g;
-            const double v = g0 * te[e] + g1 * te[NTE + e] + g2 * te[2 * NTE + e];
+            const double v = g0 * te[e] + g1 * te[NTES + e] + g2 * te[2 * NTES + e];
             Te[h][g] = v;
             Te[g][h] = v;
           }
@@ -592,7 +606,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 #pragma unroll
       for (int q = 0; q < NDIV; ++q)
         full[2 * K + q] = sgn * Rq[1 + q];
-      const double* wq = row16<AL>(sWQ + ci * 3 * NH * NCOL);
+      const double* wq = row16<AL>(sWQ + ci * 3 * NH * NCOLS);
 #pragma unroll
       for (int h = 0; h < NH; ++h)
       {
@@ -600,14 +614,15 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         if constexpr (AL)
         {
 #pragma unroll
-          for (int c2 = 0; c2 < NCOL / 2; ++c2)
+          for (int c2 = 0; c2 < NCOLS / 2; ++c2)
           {
-            const double2 w0 = reinterpret_cast<const double2*>(wq + h * NCOL)[c2];
-            const double2 w1 = reinterpret_cast<const double2*>(wq + (NH + h) * NCOL)[c2];
-            const double2 w2 = reinterpret_cast<const double2*>(wq + (2 * NH + h) * NCOL)[c2];
-            s0 += w0.x * full[2 * c2] + w0.y * full[2 * c2 + 1];
-            s1 += w1.x * full[2 * c2] + w1.y * full[2 * c2 + 1];
-            s2 += w2.x * full[2 * c2] + w2.y * full[2 * c2 + 1];
+            const double2 w0 = reinterpret_cast<const double2*>(wq + h * NCOLS)[c2];
+            const double2 w1 = reinterpret_cast<const double2*>(wq + (NH + h) * NCOLS)[c2];
+            const double2 w2 = reinterpret_cast<const double2*>(wq + (2 * NH + h) * NCOLS)[c2];
+            const double f0 = full[2 * c2], f1 = (2 * c2 + 1 < NCOL) ? full[2 * c2 + 1] : 0.0; // pad column
+            s0 += w0.x * f0 + w0.y * f1;
+            s1 += w1.x * f0 + w1.y * f1;
+            s2 += w2.x * f0 + w2.y * f1;
           }
         }
         else
@@ -615,9 +630,9 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 #pragma unroll
           for (int c = 0; c < NCOL; ++c)
           {
-            s0 += wq[h * NCOL + c] * full[c];
-            s1 += wq[(NH + h) * NCOL + c] * full[c];
-            s2 += wq[(2 * NH + h) * NCOL + c] * full[c];
+            s0 += wq[h * NCOLS + c] * full[c];
+            s1 += wq[(NH + h) * NCOLS + c] * full[c];
+            s2 += wq[(2 * NH + h) * NCOLS + c] * full[c];
           }
         }
         Le[h] = -(g0 * s0 + g1 * s1 + g2 * s2);

@@ -133,14 +133,14 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
     const double g0 = (J[0][0] * J[0][0] + J[1][0] * J[1][0]) * ia,
                  g1 = (J[0][0] * J[0][1] + J[1][0] * J[1][1]) * ia,
                  g2 = (J[0][1] * J[0][1] + J[1][1] * J[1][1]) * ia;
-    const double* te = sTE + ci * 3 * NTE;
+    const double* te = sTE + ci * 3 * Z::NTES;
 #pragma unroll
     for (int h = 0; h < NH; ++h)
 #pragma unroll
       for (int g = 0; g <= h; ++g)
       {
         const int e = h * (h + 1) / 2 + g;
-        const double v = g0 * te[e] + g1 * te[NTE + e] + g2 * te[2 * NTE + e];
+        const double v = g0 * te[e] + g1 * te[Z::NTES + e] + g2 * te[2 * Z::NTES + e];
         Te[h][g] = v;
         Te[g][h] = v;
       }
@@ -816,7 +816,7 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
     const double g0 = (J[0][0] * J[0][0] + J[1][0] * J[1][0]) * ia,
                  g1 = (J[0][0] * J[0][1] + J[1][0] * J[1][1]) * ia,
                  g2 = (J[0][1] * J[0][1] + J[1][1] * J[1][1]) * ia;
-    const double* te = sTE + ci * 3 * NTE;
+    const double* te = sTE + ci * 3 * Z::NTES;
 #pragma unroll
     for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -825,7 +825,7 @@ __global__ void __launch_bounds__(256, EQLB_WS_LEAN_WAVES) k_se_weaksym_lean(con
         const int hh = (h > g) ? h : g, gg = (h > g) ? g : h;
         const int e = hh * (hh + 1) / 2 + gg;
         if (gi[h] >= gi[g])
-          atomicAdd(&Lg[tri(gi[h], gi[g])], g0 * te[e] + g1 * te[NTE + e] + g2 * te[2 * NTE + e]);
+          atomicAdd(&Lg[tri(gi[h], gi[g])], g0 * te[e] + g1 * te[Z::NTES + e] + g2 * te[2 * Z::NTES + e]);
       }
     double Lce[3] = {0.0, 0.0, 0.0};
 #pragma unroll
