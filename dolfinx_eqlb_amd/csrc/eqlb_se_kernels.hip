@@ -1593,7 +1593,7 @@ constexpr int tile_threads_c(int k) { return (k >= 3) ? EQLB_TILE_THREADS_K3 : E
 #define EQLB_TILE_CELLS 480 // 480 cells x 18 packed values + tables: two workgroups per CU (SE and EV)
 #endif
 #ifndef EQLB_TILE_CELLS_K3
-#define EQLB_TILE_CELLS_K3 160 // 160 cells x 36 packed values + 30 KB of tables: two workgroups per CU
+#define EQLB_TILE_CELLS_K3 160 // 160 cells x 36 packed values + 32 KB of tables: two workgroups per CU
 #endif
 constexpr int tile_cells_c(int k) { return (k >= 3) ? EQLB_TILE_CELLS_K3 : EQLB_TILE_CELLS; }
 int tile_cells_of(int k) { return tile_cells_c(k); }
