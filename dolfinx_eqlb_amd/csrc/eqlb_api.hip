@@ -1120,7 +1120,10 @@ int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, dou
   if (!name || !out || eqlb::fill_tables_host(k, degree_dg, tab) != 0)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_get_reference_table: unknown table");
   const int nrt = k * (k + 2), nd = (degree_dg + 1) * (degree_dg + 2) / 2, nq = k * (k + 1) / 2;
-  const size_t nS = (size_t)3 * nrt * nrt, nF = (size_t)9 * nd * k, nH = (size_t)3 * nd * nq,
+  // layout of the table buffer (fill_tables_host): S | F | H | D | ...; the three rows of H are padded
+  // to an even number of doubles there (Sizes::HROW) and returned without the padding
+  const size_t hrow = (size_t)nd * nq, hrow_pad = hrow + (hrow & 1);
+  const size_t nS = (size_t)3 * nrt * nrt, nF = (size_t)9 * nd * k, nH = 3 * hrow, nHp = 3 * hrow_pad,
                nD = (size_t)6 * nd * nq;
   size_t off = 0, len = 0;
   if (!strcmp(name, "S"))
@@ -1135,12 +1138,16 @@ int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, dou
   }
   else if (!strcmp(name, "H"))
   {
-    off = nS + nF;
-    len = nH;
+    if ((size_t)capacity < nH)
+      return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_get_reference_table: capacity too small");
+    for (int n = 0; n < 3; ++n)
+      std::copy(tab.begin() + nS + nF + n * hrow_pad, tab.begin() + nS + nF + n * hrow_pad + hrow,
+                out + n * hrow);
+    return (int)nH;
   }
   else if (!strcmp(name, "D"))
   {
-    off = nS + nF + nH;
+    off = nS + nF + nHp;
     len = nD;
   }
   else
