@@ -13,11 +13,14 @@
 // prefix sum fixes the zero-order moments (the recurrence of :581,844,876-901), and the reduced
 // SPD system in [d | (k-1) moments per patch facet | interior DOFs per cell] is solved either
 //   SOLVER 0: dense Cholesky of the patch tile in LDS, cooperatively by the P lanes, or
-//   SOLVER 1: block-tridiagonal (+ border) elimination held in registers, passed lane to lane
-//             with shuffles (no LDS traffic).
+//   SOLVER 1: block-tridiagonal (+ border) system held in registers: parallel cyclic reduction over
+//             the lanes of a patch with DPP row shifts for P <= 16 (scalar blocks for RT_2, 2 x 2
+//             blocks for RT_3), sequential lane-to-lane elimination for the large-valence bins.
 // Result scatter: SCATTER 0 writes each (cell, vertex) contribution once into a slot buffer that
 // a streaming kernel reduces in fixed order (bitwise reproducible); SCATTER 1 uses fp64 global
-// atomics.  DESIGN.md derives the formulation; tests/proto_gpu_math.py is its numpy statement.
+// atomics; SCATTER 2 (k_se_patch_tiled, the default for k <= 2) keeps the rows of a tile of cells in
+// LDS and adds them to flux_hdiv in the same launch.  DESIGN.md derives the formulation and logs
+// the measurements behind every variant; tests/proto_gpu_math.py is its numpy statement.
 #include "eqlb_device_common.h"
 #include "eqlb_tables_gen.h"
 
