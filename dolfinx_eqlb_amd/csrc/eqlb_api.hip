@@ -158,7 +158,51 @@ struct TileItem
   int32_t cell;
 };
 
-void rcb_split(TileItem* a, int64_t n, int64_t ntile, int tc)
+// Context of the bisection: cell -> nodes and a per-node stamp to count the nodes a cut separates
+struct RcbCtx
+{
+  const int32_t* cell_nodes;
+  std::vector<int64_t> stamp; // [nnodes] 2 * epoch + side of the last cell that touched the node
+  std::vector<int64_t> cut;   // [nnodes] epoch in which the node was counted as cut
+  int64_t epoch = 0;
+};
+
+static void rcb_partition(TileItem* a, int64_t n, int64_t nl, int axis)
+{
+  if (axis == 0)
+    std::nth_element(a, a + nl, a + n, [](const TileItem& p, const TileItem& q) {
+      return p.x < q.x || (p.x == q.x && p.cell < q.cell);
+    });
+  else
+    std::nth_element(a, a + nl, a + n, [](const TileItem& p, const TileItem& q) {
+      return p.y < q.y || (p.y == q.y && p.cell < q.cell);
+    });
+}
+
+// nodes with cells on both sides of the partition [0, nl) | [nl, n): their patches are solved twice
+static int64_t rcb_cut_nodes(const TileItem* a, int64_t n, int64_t nl, RcbCtx& c)
+{
+  const int64_t ep = ++c.epoch;
+  int64_t ncut = 0;
+  for (int64_t i = 0; i < n; ++i)
+  {
+    const int64_t tag = 2 * ep + (i < nl ? 0 : 1);
+    const int32_t* cn = c.cell_nodes + 3 * (size_t)a[i].cell;
+    for (int j = 0; j < 3; ++j)
+    {
+      int64_t& st = c.stamp[cn[j]];
+      if (st / 2 == ep && st != tag && c.cut[cn[j]] != ep)
+      {
+        c.cut[cn[j]] = ep;
+        ++ncut;
+      }
+      st = tag;
+    }
+  }
+  return ncut;
+}
+
+void rcb_split(TileItem* a, int64_t n, int64_t ntile, int tc, RcbCtx& c)
 {
   if (ntile <= 1 || n <= tc)
     return;
@@ -172,16 +216,25 @@ void rcb_split(TileItem* a, int64_t n, int64_t ntile, int tc)
   }
   const int64_t tl = ntile / 2;
   const int64_t nl = std::min<int64_t>(n, tl * tc);
-  if (hi[0] - lo[0] >= hi[1] - lo[1])
-    std::nth_element(a, a + nl, a + n, [](const TileItem& p, const TileItem& q) {
-      return p.x < q.x || (p.x == q.x && p.cell < q.cell);
-    });
+  int axis = (hi[0] - lo[0] >= hi[1] - lo[1]) ? 0 : 1;
+  // the last levels decide the shape of the tiles: there the cut is chosen by what it costs - the
+  // nodes it separates - not by the extent of the bounding box (which misleads on stretched cells:
+  // boundary layers, polar meshes)
+  if (ntile <= 64)
+  {
+    rcb_partition(a, n, nl, axis);
+    const int64_t c0 = rcb_cut_nodes(a, n, nl, c);
+    rcb_partition(a, n, nl, 1 - axis);
+    const int64_t c1 = rcb_cut_nodes(a, n, nl, c);
+    if (c1 < c0)
+      axis = 1 - axis; // already partitioned along it
+    else
+      rcb_partition(a, n, nl, axis);
+  }
   else
-    std::nth_element(a, a + nl, a + n, [](const TileItem& p, const TileItem& q) {
-      return p.y < q.y || (p.y == q.y && p.cell < q.cell);
-    });
-  rcb_split(a, nl, tl, tc);
-  rcb_split(a + nl, n - nl, ntile - tl, tc);
+    rcb_partition(a, n, nl, axis);
+  rcb_split(a, nl, tl, tc, c);
+  rcb_split(a + nl, n - nl, ntile - tl, tc, c);
 }
 
 // Tiled SoA of the plain flux equilibration (EQLB_SCATTER_TILED): cells bisected recursively by
@@ -204,7 +257,8 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin, eqlb::BuildArgs
     items[c] = {cx, cy, c};
   }
   const int32_t ntiles = (nc + TC - 1) / TC;
-  rcb_split(items.data(), nc, ntiles, TC);
+  RcbCtx rctx{m.h_cell_nodes.data(), std::vector<int64_t>(m.nnodes, -1), std::vector<int64_t>(m.nnodes, -1), 0};
+  rcb_split(items.data(), nc, ntiles, TC, rctx);
   // ascending cell ids inside a tile: the flush of a tile then touches flux_hdiv in long runs
   for (int32_t t = 0; t < ntiles; ++t)
     std::sort(items.begin() + (size_t)t * TC, items.begin() + std::min<size_t>((size_t)(t + 1) * TC, nc),
