@@ -141,7 +141,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 {
   using Z = Sizes<K, DEG, P>;
   constexpr int KB = Z::KB, NADD = Z::NADD, NDIV = Z::NDIV, NRT = Z::NRT, ND = Z::ND, NQ = Z::NQ;
-  constexpr int NCOL = Z::NCOL, NH = Z::NH, NTE = Z::NTE;
+  constexpr int NCOL = Z::NCOL, NH = Z::NH;
 
   // RT_2 with P1 data: every segment and every row used below has an even number of doubles, the
   // rows start on 16-byte boundaries (the dynamic LDS segment does): 128-bit LDS reads
