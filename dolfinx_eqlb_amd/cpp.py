@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = [
     "eqlb_ev_last_kernel_ms", "eqlb_se_tiling_info", "eqlb_se_estimate",
     "eqlb_halo_pack", "eqlb_halo_unpack_add", "eqlb_ev_estimate",
     "eqlb_se_check_status", "eqlb_ev_check_status",
+    "eqlb_se_set_priority_cells", "eqlb_se_num_priority_tiles",
 ]
 
 _lib = None
@@ -189,6 +190,15 @@ class SemiExplicitEquilibrator:
         _check(lib().eqlb_se_equilibrate(self._h, C.c_void_p(flux_dg_ptr), C.c_void_p(rhs_dg_ptr),
                                          C.c_void_p(flux_hdiv_ptr), C.c_int32(MEM_DEVICE),
                                          C.c_void_p(stream)))
+
+    def set_priority_cells(self, cells):
+        """Cells whose tiles become the first tiles at the next set_boundary (two-phase sweeps)."""
+        c = np.ascontiguousarray(cells, dtype=np.int32)
+        _check(lib().eqlb_se_set_priority_cells(self._h, _hp(c), C.c_int32(c.size)))
+
+    @property
+    def num_priority_tiles(self) -> int:
+        return int(lib().eqlb_se_num_priority_tiles(self._h))
 
     def check_status(self, stream: int = 0):
         """After device-memory calls: waits for the stream and raises if a patch system was not

@@ -263,13 +263,37 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin, eqlb::BuildArgs
   for (int32_t t = 0; t < ntiles; ++t)
     std::sort(items.begin() + (size_t)t * TC, items.begin() + std::min<size_t>((size_t)(t + 1) * TC, nc),
               [](const TileItem& p, const TileItem& q) { return p.cell < q.cell; });
-  std::vector<int32_t> tile_cells((size_t)ntiles * TC, -1), cell_tile(nc), cell_pos(nc);
-  for (int32_t p = 0; p < nc; ++p)
+  // tiles that own a priority cell (ghost rows a neighbour rank waits for) are numbered first: a
+  // first launch over them, the halo exchange, and the launch over the rest then overlap
+  std::vector<int32_t> order(ntiles);
   {
-    const int32_t c = items[p].cell;
-    tile_cells[p] = c;
-    cell_tile[c] = p / TC;
-    cell_pos[c] = p;
+    std::vector<uint8_t> is_prio(nc, 0), tile_prio(ntiles, 0);
+    for (int32_t c : h->prio_cells)
+      if (c >= 0 && c < nc)
+        is_prio[c] = 1;
+    for (int32_t p = 0; p < nc; ++p)
+      if (is_prio[items[p].cell])
+        tile_prio[p / TC] = 1;
+    int32_t np = 0;
+    for (int32_t t = 0; t < ntiles; ++t)
+      if (tile_prio[t])
+        order[np++] = t;
+    h->t_nprio = np;
+    for (int32_t t = 0; t < ntiles; ++t)
+      if (!tile_prio[t])
+        order[np++] = t;
+  }
+  std::vector<int32_t> tile_cells((size_t)ntiles * TC, -1), cell_tile(nc), cell_pos(nc);
+  for (int32_t t = 0; t < ntiles; ++t)
+  {
+    const int64_t src = (int64_t)order[t] * TC, len = std::min<int64_t>(TC, nc - src);
+    for (int64_t q = 0; q < len; ++q)
+    {
+      const int32_t c = items[src + q].cell;
+      tile_cells[(size_t)t * TC + q] = c;
+      cell_tile[c] = t;
+      cell_pos[c] = (int32_t)((int64_t)t * TC + q);
+    }
   }
   std::vector<eqlb::TileDesc> tiles(ntiles);
   std::vector<int32_t> inst_node, inst_slot, inst_tile, stamp(m.nnodes, -1);
@@ -595,6 +619,14 @@ int eqlb_se_set_option(eqlb_se_t* h, const char* key, int32_t value)
     h->timing = value;
     h->ev_calls = 0;
   }
+  else if (!strcmp(key, "tile_first"))
+  {
+    if (value < 0)
+      return fail(EQLB_ERR_INVALID_ARGUMENT, "tile_first must not be negative");
+    h->tile_first = value;
+  }
+  else if (!strcmp(key, "tile_count"))
+    h->tile_count = value;
   else
     return fail(EQLB_ERR_INVALID_ARGUMENT, "unknown option '%s'", key);
   return EQLB_OK;
@@ -799,6 +831,16 @@ int eqlb_se_tiling_info(const eqlb_se_t* h, int64_t* ntiles, int64_t* cells_per_
   return EQLB_OK;
 }
 
+int eqlb_se_set_priority_cells(eqlb_se_t* h, const int32_t* cells, int32_t n)
+{
+  if (!h || n < 0 || (n > 0 && !cells))
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_set_priority_cells: invalid argument");
+  h->prio_cells.assign(cells, cells + n);
+  return EQLB_OK;
+}
+
+int32_t eqlb_se_num_priority_tiles(const eqlb_se_t* h) { return (h && h->boundary_set) ? h->t_nprio : 0; }
+
 int eqlb_se_export_patches(eqlb_se_t* h, int32_t stride, int32_t* ncells, int32_t* cells,
                            int32_t* fcts, int8_t* fcts_local, int8_t* inodes_local,
                            int8_t* reversed)
@@ -959,9 +1001,13 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
     if (h->stress || h->solver != EQLB_SOLVER_SHUFFLE || h->ntiles == 0)
       return fail(EQLB_ERR_UNSUPPORTED,
                   "the tiled scatter is available for k <= 2 flux equilibration with the shuffle solver");
-    eqlb::TileArgs ta{h->t_tiles, h->t_tile_cells, h->ntiles, h->tile_tc,
+    if (h->tile_first > h->ntiles)
+      return fail(EQLB_ERR_INVALID_ARGUMENT, "tile_first %d beyond the %d tiles", h->tile_first, h->ntiles);
+    const int32_t tcount = (h->tile_count < 0) ? h->ntiles - h->tile_first
+                                               : std::min(h->tile_count, h->ntiles - h->tile_first);
+    eqlb::TileArgs ta{h->t_tiles, h->t_tile_cells, tcount, h->tile_tc,
                       ev_conf ? h->t_facet_owner : nullptr, h->ev_cell_dofs, h->ev_ndofs, m.nfacets,
-                      h->t_masked ? 1 : 0};
+                      h->t_masked ? 1 : 0, h->tile_first};
     a.slot_cell = h->t_slot_cell;
     a.slot_info = h->t_slot_info;
     a.pn = h->t_pn;

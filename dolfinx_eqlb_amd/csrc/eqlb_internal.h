@@ -109,6 +109,7 @@ struct TileArgs
   int64_t ndofs;
   int32_t nfacets;
   int32_t zero_slots; // 1: some (cell, vertex) rows are never written (node_mask): zero the LDS slots
+  int32_t tile_first; // this launch handles the tiles [tile_first, tile_first + ntiles)
 };
 
 struct BuildArgs
@@ -232,6 +233,10 @@ struct eqlb_se
   uint32_t* t_slot_info = nullptr;
   uint8_t *t_pn = nullptr, *t_pflag = nullptr;
   bool t_masked = false;            // set_boundary got a node_mask (tiles then hold unwritten rows)
+  // two-phase sweeps (multi-GPU overlap): tiles owning a priority cell are numbered first
+  std::vector<int32_t> prio_cells;
+  int32_t t_nprio = 0;              // number of priority tiles
+  int32_t tile_first = 0, tile_count = -1; // options "tile_first" / "tile_count" (-1: to the end)
   double* slots = nullptr;          // [nrhs][ncells][3][nrt]
   int32_t* status = nullptr;
   // staging for host-memory calls

@@ -1674,7 +1674,7 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
   // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, tiles are numbered along the
   // bisection tree (neighbours in space are neighbours in index); give every XCD one contiguous
   // range of tiles so that the rim cells two tiles share are read through the same L2
-  const int tile = xcd_remap(blockIdx.x, ta.ntiles);
+  const int tile = ta.tile_first + xcd_remap(blockIdx.x, ta.ntiles);
   constexpr int NTABM = Z::NTAB + (MODE ? Z::NEV : 0);
   double* sSlots = lds + NTABM;
   for (int i = threadIdx.x; i < Z::NTAB; i += TILE_THREADS)

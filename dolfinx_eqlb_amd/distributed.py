@@ -100,6 +100,12 @@ class HaloExchange:
         and clears the ghost rows (their content now lives on the owner).  Device tensors use the
         two halo kernels of libeqlb_amd.so (one launch each) around the RCCL send/recv; CPU tensors
         (gloo tests) use plain indexing."""
+        return self.finish(x, self.start(x))
+
+    def start(self, x):
+        """First half: pack the ghost rows (final once the tiles that own them have run) and post
+        the send / receive.  Work enqueued on the current stream after this call overlaps the
+        transfer; finish() orders the unpack behind it."""
         import torch
         import torch.distributed as dist
         part = self.part
@@ -119,14 +125,24 @@ class HaloExchange:
             ops.append(dist.P2POp(dist.isend, self.send_buf, part.rank + 1))
         if nr:
             ops.append(dist.P2POp(dist.irecv, self.recv_buf, part.rank - 1))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def finish(self, x, reqs):
+        """Second half: wait for the transfer (the current stream waits, not the host) and add the
+        received partial sums to the owned rows."""
+        import torch
+        part = self.part
+        on_gpu = x.is_cuda
+        nr = int(part.recv_cells.size)
+        for req in reqs:
+            req.wait()
         if nr:
             if on_gpu:
                 from . import cpp
+                stream = torch.cuda.current_stream().cuda_stream
                 cpp.halo_unpack_add(x.data_ptr(), self.recv_idx.data_ptr(), self.recv_buf.data_ptr(),
                                     self.nrhs, nr, self.nrt, part.mesh.ncells, stream)
             else:
+                xv = x.view(self.nrhs, part.mesh.ncells, self.nrt)
                 xv[:, self.recv_idx, :] += self.recv_buf
         return x

@@ -204,6 +204,15 @@ int32_t eqlb_mesh_max_patch_cells(const eqlb_mesh_t* mesh);
 int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, double* out,
                              int32_t capacity);
 
+/* Two-phase sweeps of the tiled launch (multi-GPU: the reference has no distributed equilibration,
+ * SURVEY 8e).  Cells listed here before eqlb_se_set_boundary - the ghost cells whose rows a
+ * neighbour rank waits for - make their tiles the FIRST tiles; eqlb_se_num_priority_tiles returns how
+ * many there are.  With the options "tile_first" / "tile_count" (eqlb_se_set_option; count -1 = to the
+ * end) an equilibrate call sweeps a range of tiles only: first the priority tiles, then - while the
+ * halo exchange of their rows is in flight - the rest.  Tiled scatter only. */
+int eqlb_se_set_priority_cells(eqlb_se_t* handle, const int32_t* cells, int32_t n);
+int32_t eqlb_se_num_priority_tiles(const eqlb_se_t* handle);
+
 /* Device-memory calls (EQLB_MEM_DEVICE) return without synchronising, so a patch system that is not
  * positive definite (degenerate cell geometry; the matrix does not depend on the data) cannot be
  * reported by the call itself: the kernels raise a flag on the device.  eqlb_se_check_status waits for `stream`, reads and clears

@@ -106,3 +106,71 @@ def test_device_calls_report_bad_patches_through_check_status(ev):
     with pytest.raises(RuntimeError):
         eq.check_status(stream)
     eq.check_status(stream)  # the flag was cleared
+
+
+def test_two_phase_sweep_with_halo_between(oracle_mod):
+    """The multi-GPU step of bench.py on ONE device: tiles owning ghost cells first (priority
+    tiles), the ghost rows packed and 'sent' while the remaining tiles are swept, unpack at the end -
+    the result must equal the single-domain reference, and the priority tiles must own every
+    ghost cell."""
+    import torch
+    from dolfinx_eqlb_amd import cpp
+    from dolfinx_eqlb_amd import distributed as dd
+    from dolfinx_eqlb_amd.mesh import create_rectangle
+    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    world, n, k = 3, 24, 2
+    nrt = k * (k + 2)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    gmesh = create_rectangle(world * n, n, 0.0, float(world))
+    gft = facet_types(gmesh)
+    gG, gf = make_compatible_data(gmesh, k, gft, seed=5)
+    gref = oracle_mod.se_reconstruct(gmesh, k, gft, gG[None], gf[None])[0].reshape(gmesh.ncells, nrt)
+    parts, xs, gcells, bufs = [], [], [], []
+    for rank in range(world):
+        part = dd.StripPartition(n, rank, world)
+        gi, gj, gt = part.grid_ids
+        gcell = (gj * (world * n) + gi + rank * n) * 4 + gt
+        m = part.mesh
+        G = gG.reshape(gmesh.ncells, -1)[gcell].ravel()
+        f = gf.reshape(gmesh.ncells, -1)[gcell].ravel()
+        eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(m), k, 1)
+        eq.set_priority_cells(part.send_cells)
+        eq.set_boundary(part.facet_types(), node_mask=part.node_mask)
+        ti = eq.tiling_info()
+        nprio = eq.num_priority_tiles
+        assert ti["ntiles"] >= 4
+        if part.send_cells.size:
+            assert 0 < nprio < ti["ntiles"]
+        else:
+            assert nprio == 0
+        x = torch.zeros(m.ncells * nrt, dtype=torch.float64, device=dev)
+        dG, df = torch.from_numpy(G).to(dev), torch.from_numpy(f).to(dev)
+        sidx = torch.from_numpy(part.send_cells).to(dev)
+        buf = torch.zeros(max(sidx.numel(), 1) * nrt, dtype=torch.float64, device=dev)
+        # phase 1: priority tiles, then the ghost rows leave (they must be final here)
+        eq.set_option("tile_first", 0)
+        eq.set_option("tile_count", nprio)
+        eq.equilibrate_device(dG.data_ptr(), df.data_ptr(), x.data_ptr(), stream)
+        if sidx.numel():
+            cpp.halo_pack(x.data_ptr(), sidx.data_ptr(), buf.data_ptr(), 1, sidx.numel(), nrt,
+                          m.ncells, True, stream)
+        # phase 2: the rest of the tiles
+        eq.set_option("tile_first", nprio)
+        eq.set_option("tile_count", -1)
+        eq.equilibrate_device(dG.data_ptr(), df.data_ptr(), x.data_ptr(), stream)
+        torch.cuda.synchronize()
+        parts.append(part)
+        xs.append(x)
+        gcells.append(gcell)
+        bufs.append(buf)
+    for r in range(1, world):
+        ridx = torch.from_numpy(parts[r].recv_cells).to(dev)
+        cpp.halo_unpack_add(xs[r].data_ptr(), ridx.data_ptr(), bufs[r - 1].data_ptr(), 1, ridx.numel(),
+                            nrt, parts[r].mesh.ncells, stream)
+    torch.cuda.synchronize()
+    for r in range(world):
+        own = parts[r].cell_owned
+        got = xs[r].cpu().numpy().reshape(-1, nrt)[own]
+        ref = gref[gcells[r][own]]
+        assert np.abs(got - ref).max() <= 1e-10 * np.abs(gref).max()
