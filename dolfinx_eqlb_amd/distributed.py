@@ -94,6 +94,7 @@ class HaloExchange:
         self.recv_idx = torch.from_numpy(part.recv_cells).to(device)
         self.send_buf = torch.zeros((nrhs, part.send_cells.size, nrt), dtype=torch.float64, device=device)
         self.recv_buf = torch.zeros((nrhs, part.recv_cells.size, nrt), dtype=torch.float64, device=device)
+        self._ops = None
 
     def reduce(self, x):
         """x: [nrhs * ncells * nrt] tensor; adds the neighbour's partial sums to the owned rows
@@ -122,10 +123,13 @@ class HaloExchange:
             else:
                 self.send_buf.copy_(xv[:, self.send_idx, :])
                 xv[:, self.send_idx, :] = 0.0
-            ops.append(dist.P2POp(dist.isend, self.send_buf, part.rank + 1))
-        if nr:
-            ops.append(dist.P2POp(dist.irecv, self.recv_buf, part.rank - 1))
-        return dist.batch_isend_irecv(ops) if ops else []
+        if self._ops is None:  # the descriptors are reused: same buffers, same peers every step
+            if ns:
+                ops.append(dist.P2POp(dist.isend, self.send_buf, part.rank + 1))
+            if nr:
+                ops.append(dist.P2POp(dist.irecv, self.recv_buf, part.rank - 1))
+            self._ops = ops
+        return dist.batch_isend_irecv(self._ops) if self._ops else []
 
     def finish(self, x, reqs):
         """Second half: wait for the transfer (the current stream waits, not the host) and add the
