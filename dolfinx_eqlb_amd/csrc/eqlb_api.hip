@@ -311,6 +311,8 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin, eqlb::BuildArgs
       for (int j = 0; j < 3; ++j)
       {
         const int32_t nd = m.h_cell_nodes[3 * (size_t)c + j];
+        if (node_bin[nd] < 0)
+          tiles[t].zero = 1; // masked-out vertex: the (cell, vertex) row of this tile stays unwritten
         if (node_bin[nd] < 0 || stamp[nd] == t)
           continue;
         stamp[nd] = t;
@@ -663,7 +665,6 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
       return fail(EQLB_ERR_INVALID_ARGUMENT, "node %d belongs to no cell", i);
   }
   free_boundary(h);
-  h->t_masked = node_mask != nullptr;
 
   // bins by lanes per patch: P = smallest of {4,8,16,32,64} >= number of patch facets
   std::vector<int64_t> node_slot(m.nnodes, -1), node_patch(m.nnodes, -1);
@@ -1007,7 +1008,7 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
                                                : std::min(h->tile_count, h->ntiles - h->tile_first);
     eqlb::TileArgs ta{h->t_tiles, h->t_tile_cells, tcount, h->tile_tc,
                       ev_conf ? h->t_facet_owner : nullptr, h->ev_cell_dofs, h->ev_ndofs, m.nfacets,
-                      h->t_masked ? 1 : 0, h->tile_first};
+                      h->tile_first};
     a.slot_cell = h->t_slot_cell;
     a.slot_info = h->t_slot_info;
     a.pn = h->t_pn;

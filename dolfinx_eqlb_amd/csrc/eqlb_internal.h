@@ -96,6 +96,8 @@ struct TileDesc
   int32_t patch_start[MAX_BINS];
   int32_t npatch[MAX_BINS];
   int32_t nfull[MAX_BINS]; // leading patches of the bin that are interior with exactly P cells
+  int32_t zero;            // 1: a vertex of an owned cell is not equilibrated here (node mask): its row
+                           // is never written, the LDS slots of the tile are zeroed first
 };
 
 struct TileArgs
@@ -108,7 +110,6 @@ struct TileArgs
   const int32_t* cell_dofs;   // caller's dofmap or nullptr (default numbering)
   int64_t ndofs;
   int32_t nfacets;
-  int32_t zero_slots; // 1: some (cell, vertex) rows are never written (node_mask): zero the LDS slots
   int32_t tile_first; // this launch handles the tiles [tile_first, tile_first + ntiles)
 };
 
@@ -232,7 +233,6 @@ struct eqlb_se
   int32_t *t_tile_cells = nullptr, *t_slot_cell = nullptr, *t_facet_owner = nullptr;
   uint32_t* t_slot_info = nullptr;
   uint8_t *t_pn = nullptr, *t_pflag = nullptr;
-  bool t_masked = false;            // set_boundary got a node_mask (tiles then hold unwritten rows)
   // two-phase sweeps (multi-GPU overlap): tiles owning a priority cell are numbered first
   std::vector<int32_t> prio_cells;
   int32_t t_nprio = 0;              // number of priority tiles

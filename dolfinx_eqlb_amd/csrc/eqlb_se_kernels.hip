@@ -1683,8 +1683,9 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
     for (int i = threadIdx.x; i < Z::NEV; i += TILE_THREADS)
       lds[Z::NTAB + i] = a0.tables[Z::OFF_HG + i];
   // every packed row of an owned cell is written completely by the patch of its vertex; rows of
-  // vertices that this rank does not equilibrate (node_mask) must read as zero in the flush
-  if (ta.zero_slots)
+  // vertices that this rank does not equilibrate (node mask; flagged per tile) must read as zero in
+  // the flush
+  if (ta.tiles[tile].zero)
     for (int i = threadIdx.x; i < TC * 3 * NPK; i += TILE_THREADS)
       sSlots[i] = 0.0;
   __syncthreads();
