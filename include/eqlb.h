@@ -106,7 +106,9 @@ void eqlb_se_destroy(eqlb_se_t* handle);
 
 /* Integer options: "solver" (EQLB_SOLVER_*; default SHUFFLE, LDS_CHOLESKY for k = 4), "scatter"
  * (EQLB_SCATTER_*; default AUTO), "fused" (1: all patch-size bins of the slot path in one launch,
- * default), "timing" (1: record HIP events around the kernels, see eqlb_se_last_kernel_ms). */
+ * default), "timing" (1: record HIP events around the kernels, see eqlb_se_last_kernel_ms),
+ * "tile_first" / "tile_count" (range of tiles swept by the next tiled launches, default 0 / -1 = all;
+ * see eqlb_se_set_priority_cells). */
 int eqlb_se_set_option(eqlb_se_t* handle, const char* key, int32_t value);
 
 /*
