@@ -130,19 +130,16 @@ def main():
     halo = dd.HaloExchange(part, nrt, dev) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
 
+    pG, pf, px = d_G.data_ptr(), d_f.data_ptr(), d_x.data_ptr()
     two_phase = halo is not None and not args.ev and args.scatter == 2
     nprio = eq.num_priority_tiles if two_phase else 0
 
     def step():
         if two_phase:
             # tiles owning ghost cells, then the reverse halo of their rows in flight behind the rest
-            eq.set_option("tile_first", 0)
-            eq.set_option("tile_count", nprio)
-            eq.equilibrate_device(d_G.data_ptr(), d_f.data_ptr(), d_x.data_ptr(), stream)
+            eq.equilibrate_device_tiles(pG, pf, px, 0, nprio, stream)
             reqs = halo.start(d_x)
-            eq.set_option("tile_first", nprio)
-            eq.set_option("tile_count", -1)
-            eq.equilibrate_device(d_G.data_ptr(), d_f.data_ptr(), d_x.data_ptr(), stream)
+            eq.equilibrate_device_tiles(pG, pf, px, nprio, -1, stream)
             halo.finish(d_x, reqs)
             return
         eq.equilibrate_device(d_G.data_ptr(), d_f.data_ptr(), d_x.data_ptr(), stream)

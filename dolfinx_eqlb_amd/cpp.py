@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "eqlb_ev_last_kernel_ms", "eqlb_se_tiling_info", "eqlb_se_estimate",
     "eqlb_halo_pack", "eqlb_halo_unpack_add", "eqlb_ev_estimate",
     "eqlb_se_check_status", "eqlb_ev_check_status",
-    "eqlb_se_set_priority_cells", "eqlb_se_num_priority_tiles",
+    "eqlb_se_set_priority_cells", "eqlb_se_num_priority_tiles", "eqlb_se_equilibrate_tiles",
 ]
 
 _lib = None
@@ -190,6 +190,13 @@ class SemiExplicitEquilibrator:
         _check(lib().eqlb_se_equilibrate(self._h, C.c_void_p(flux_dg_ptr), C.c_void_p(rhs_dg_ptr),
                                          C.c_void_p(flux_hdiv_ptr), C.c_int32(MEM_DEVICE),
                                          C.c_void_p(stream)))
+
+    def equilibrate_device_tiles(self, flux_dg_ptr: int, rhs_dg_ptr: int, flux_hdiv_ptr: int,
+                                 tile_first: int, tile_count: int, stream: int = 0):
+        """equilibrate_device for a range of tiles (tiled scatter; count -1 = to the end)."""
+        _check(lib().eqlb_se_equilibrate_tiles(self._h, C.c_void_p(flux_dg_ptr), C.c_void_p(rhs_dg_ptr),
+                                               C.c_void_p(flux_hdiv_ptr), C.c_int32(tile_first),
+                                               C.c_int32(tile_count), C.c_void_p(stream)))
 
     def set_priority_cells(self, cells):
         """Cells whose tiles become the first tiles at the next set_boundary (two-phase sweeps)."""

@@ -842,6 +842,20 @@ int eqlb_se_set_priority_cells(eqlb_se_t* h, const int32_t* cells, int32_t n)
 
 int32_t eqlb_se_num_priority_tiles(const eqlb_se_t* h) { return (h && h->boundary_set) ? h->t_nprio : 0; }
 
+int eqlb_se_equilibrate_tiles(eqlb_se_t* h, const double* flux_dg, const double* rhs_dg, double* flux_hdiv,
+                              int32_t tile_first, int32_t tile_count, void* stream)
+{
+  if (!h || tile_first < 0)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_equilibrate_tiles: invalid argument");
+  const int32_t f0 = h->tile_first, c0 = h->tile_count;
+  h->tile_first = tile_first;
+  h->tile_count = tile_count;
+  const int st = eqlb_se_equilibrate(h, flux_dg, rhs_dg, flux_hdiv, EQLB_MEM_DEVICE, stream);
+  h->tile_first = f0;
+  h->tile_count = c0;
+  return st;
+}
+
 int eqlb_se_export_patches(eqlb_se_t* h, int32_t stride, int32_t* ncells, int32_t* cells,
                            int32_t* fcts, int8_t* fcts_local, int8_t* inodes_local,
                            int8_t* reversed)

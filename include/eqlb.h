@@ -214,6 +214,10 @@ int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, dou
  * halo exchange of their rows is in flight - the rest.  Tiled scatter only. */
 int eqlb_se_set_priority_cells(eqlb_se_t* handle, const int32_t* cells, int32_t n);
 int32_t eqlb_se_num_priority_tiles(const eqlb_se_t* handle);
+/* eqlb_se_equilibrate on device memory for the tiles [tile_first, tile_first + tile_count) only
+ * (count -1 = to the end), without touching the "tile_first" / "tile_count" options */
+int eqlb_se_equilibrate_tiles(eqlb_se_t* handle, const double* flux_dg, const double* rhs_dg,
+                              double* flux_hdiv, int32_t tile_first, int32_t tile_count, void* stream);
 
 /* Device-memory calls (EQLB_MEM_DEVICE) return without synchronising, so a patch system that is not
  * positive definite (degenerate cell geometry; the matrix does not depend on the data) cannot be

@@ -156,9 +156,9 @@ def test_two_phase_sweep_with_halo_between(oracle_mod):
             cpp.halo_pack(x.data_ptr(), sidx.data_ptr(), buf.data_ptr(), 1, sidx.numel(), nrt,
                           m.ncells, True, stream)
         # phase 2: the rest of the tiles
-        eq.set_option("tile_first", nprio)
+        eq.set_option("tile_first", 0)
         eq.set_option("tile_count", -1)
-        eq.equilibrate_device(dG.data_ptr(), df.data_ptr(), x.data_ptr(), stream)
+        eq.equilibrate_device_tiles(dG.data_ptr(), df.data_ptr(), x.data_ptr(), nprio, -1, stream)
         torch.cuda.synchronize()
         parts.append(part)
         xs.append(x)
