@@ -163,7 +163,14 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   double* sA = sHB + Z::NHB + (MODE ? Z::NEV : 0); // SOLVER 0: per-group tiles
   (void)sA;
 
-  const int tid = threadIdx.x;
+  int tid_ = threadIdx.x;
+  // tiled EV launch: an opaque lane index keeps the compiler from hoisting the lane predicates
+  // (sub == 1, sub < n, ... for every P) out of the wave-block loops of the kernel, where they occupy
+  // registers across all bins - that kernel sits at its 128-VGPR budget and would spill (the SE kernel
+  // fits and is 1 % faster with the hoisted predicates)
+  if constexpr (SCATTER == 2 && MODE == 1)
+    asm volatile("" : "+v"(tid_));
+  const int tid = tid_;
   if (!tables_staged)
   {
     for (int i = tid; i < Z::NTAB; i += BLOCK)
