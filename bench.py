@@ -127,7 +127,7 @@ def main():
     d_G = torch.from_numpy(G).to(dev)
     d_f = torch.from_numpy(f).to(dev)
     d_x = torch.zeros(nrhs * nout, dtype=torch.float64, device=dev)
-    halo = dd.HaloExchange(part, nrt, dev) if world > 1 else None
+    halo = dd.HaloExchange(part, nrt, dev, nrhs) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
 
     pG, pf, px = d_G.data_ptr(), d_f.data_ptr(), d_x.data_ptr()
