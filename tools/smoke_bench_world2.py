@@ -18,7 +18,8 @@ class _Work:
 def main():
     import torch
     import torch.distributed as dist
-    os.environ.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    os.environ.update(WORLD_SIZE=os.environ.get("SMOKE_WORLD", "2"), RANK=os.environ.get("SMOKE_RANK", "0"),
+                      LOCAL_RANK="0")
     dist.init_process_group = lambda *a, **k: None
     dist.destroy_process_group = lambda *a, **k: None
     dist.barrier = lambda *a, **k: None
