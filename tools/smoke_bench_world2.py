@@ -31,7 +31,8 @@ def main():
             self.op, self.tensor, self.peer = op, tensor, peer
 
     dist.P2POp = P2POp
-    sys.argv = ["bench.py", "--gpus", "2", "--steps", "10", "--warmup", "2", "--n", "200"] + sys.argv[1:]
+    sys.argv = ["bench.py", "--gpus", os.environ["WORLD_SIZE"], "--steps", "10", "--warmup", "2", "--n", "200"] \
+        + sys.argv[1:]  # later flags override the defaults
     import bench
     bench.main()
 
