@@ -158,6 +158,7 @@ int launch_se_patch_tiled(int k, int deg, int mode, const SeArgs& a, const TileA
 void launch_tile_facet_owner(const DeviceMesh& m, int64_t n, const int32_t* tile_cells, int32_t* code,
                              hipStream_t stream);
 int tile_cells_of(int k);
+int tile_cells_max_of(int k);
 int launch_se_weaksym(int k, int P, bool no_flux_bcs, const SeArgs& a, hipStream_t stream);
 int launch_ev_patch_fused(int k, const SeArgs& a, const FusedBins& fb, hipStream_t stream);
 // conforming <-> broken layout of the EV equilibrator (eqlb_ev.hip); cell_dofs may be nullptr

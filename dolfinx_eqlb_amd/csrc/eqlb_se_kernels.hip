@@ -1606,7 +1606,10 @@ constexpr int tile_threads_c(int k) { return (k >= 3) ? EQLB_TILE_THREADS_K3 : E
 #define EQLB_TILE_CELLS_K3 160 // 160 cells x 36 packed values + 32 KB of tables: two workgroups per CU
 #endif
 constexpr int tile_cells_c(int k) { return (k >= 3) ? EQLB_TILE_CELLS_K3 : EQLB_TILE_CELLS; }
+// largest tile the LDS budget of two workgroups per CU allows (k <= 2: 490 x 144 B + tensors <= 80 KB)
+constexpr int tile_cells_max_c(int k) { return (k >= 3) ? EQLB_TILE_CELLS_K3 : (EQLB_TILE_CELLS > 490 ? EQLB_TILE_CELLS : 490); }
 int tile_cells_of(int k) { return tile_cells_c(k); }
+int tile_cells_max_of(int k) { return tile_cells_max_c(k); }
 
 // facet-owner table of the EV flush: for the owned cell cl of a tile and its local facet lf the
 // code 2 * facet + reversal bit if the cell is the FIRST cell of the facet (it writes the facet's
@@ -1676,7 +1679,8 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
   extern __shared__ __align__(16) double lds[];
   using Z = Sizes<K, DEG, 8>;
   constexpr int NRT = Z::NRT;
-  constexpr int TC = tile_cells_c(K);
+  constexpr int TCMAX = tile_cells_max_c(K); // sizes the register arrays of the flush
+  const int TC = ta.tc;                      // cells per tile of this SoA (<= TCMAX)
   constexpr int NPK = NRT - K; // packed (cell, vertex) row: without the facet opposite to the vertex
   // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, tiles are numbered along the
   // bisection tree (neighbours in space are neighbours in index); give every XCD one contiguous
@@ -1743,7 +1747,7 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
   double* x = a0.out + (int64_t)a0.rhs * a0.ncells * NRT;
   // (two consecutive DOFs per thread where the row length is even: 16-byte loads and stores)
   constexpr int VW = (NRT % 2 == 0) ? 2 : 1;
-  constexpr int NIT = (TC * NRT / VW + TILE_THREADS - 1) / TILE_THREADS;
+  constexpr int NIT = (TCMAX * NRT / VW + TILE_THREADS - 1) / TILE_THREADS;
   double xv[NIT][VW];
   int64_t xi[NIT];
   if (!conforming)
@@ -1865,7 +1869,7 @@ static int launch_tiled_kd(const SeArgs& a, const TileArgs& t, hipStream_t strea
   using Z = Sizes<K, DEG, 8>;
   const size_t lds_bytes
       = sizeof(double) * ((size_t)Z::NTAB + (MODE ? (size_t)Z::NEV : 0) + (size_t)t.tc * 3 * (Z::NRT - K));
-  if (lds_bytes > 160 * 1024 || t.tc != tile_cells_c(K))
+  if (lds_bytes > 160 * 1024 || t.tc < 1 || t.tc > tile_cells_max_c(K))
     return EQLB_ERR_UNSUPPORTED;
   auto kern = k_se_patch_tiled<K, DEG, MODE>;
   if (lds_bytes > 64 * 1024)
