@@ -214,14 +214,14 @@ def compatibility_residual(mesh, k, facet_type, flux_dg, rhs_dg, degree_dg=None)
     return float(np.max(np.abs(r[~fixed]))) if (~fixed).any() else 0.0
 
 
-def make_compatible_stress_data(mesh, k, facet_type, seed=20241003, neumann_flux=None):
+def make_compatible_stress_data(mesh, k, facet_type, seed=20241003, neumann_flux=None, iterative=None):
     """Two rows (G_r, f_r) of a synthetic stress problem that satisfy, for every free node a,
     the force balance of each row, (f_r, hat_a) + (G_r, grad hat_a) = 0, AND the moment balance
     (f_0, hat_a y) + (G_0, grad(hat_a y)) - (f_1, hat_a x) - (G_1, grad(hat_a x)) = 0
     (what a P_k Galerkin elasticity solution, k >= 2, provides through the test functions
     hat_a (y, -x)); the latter makes the weak-symmetry patch problems consistent.
     Corrections: f_r -= c_r in P1, G += e [[0,1],[-1,0]] with e in P1 (sparse direct solve,
-    small meshes only).  neumann_flux = [w_0, w_1]: prescribed tractions t_r = w_r . n on the flux-BC
+    below 20 000 free nodes, else - or with iterative=True - GMRES on the system condensed to e).  neumann_flux = [w_0, w_1]: prescribed tractions t_r = w_r . n on the flux-BC
     facets (both balances then carry the boundary terms).
     Returns (flux_dg [2, ncells*nd*2], rhs_dg [2, ncells*nd])."""
     if k < 2:
@@ -276,31 +276,48 @@ def make_compatible_stress_data(mesh, k, facet_type, seed=20241003, neumann_flux
         # boundary part of the moment balance: - int hat_a (y t_0 - x t_1)
         R_rot -= neumann_hat_moments(mesh, ft[0], neumann_flux[0], weight=lambda x, y: y)
         R_rot += neumann_hat_moments(mesh, ft[1], neumann_flux[1], weight=lambda x, y: x)
-    # blocks of the 3-field system, unknowns (c0, c1, e), equations (R0, R1, Rrot) = 0
-    Mh = assemble_mat(np.einsum("cq,qn,qm->cnm", w, hv, hv))                      # (hat_b, hat_a)
-    My = assemble_mat(np.einsum("cq,cq,qn,qm->cnm", w, Y, hv, hv))                # (hat_b, hat_a y)
-    Mx = assemble_mat(np.einsum("cq,cq,qn,qm->cnm", w, X, hv, hv))
-    Dy = assemble_mat(np.einsum("cq,cn,qm->cnm", w, ghat[..., 1], hv))            # (hat_b, d_y hat_a)
-    Dx = assemble_mat(np.einsum("cq,cn,qm->cnm", w, ghat[..., 0], hv))
-    # (hat_b, 2 hat_a + x . grad hat_a)
-    Er = assemble_mat(2 * np.einsum("cq,qn,qm->cnm", w, hv, hv)
-                      + np.einsum("cq,cqd,cnd,qm->cnm", w, xq, ghat, hv))
-    Z = sp.csr_matrix((nn, nn))
-    # R0 + (-Mh c0) + (e, d_y hat_a) = 0 ; R1 + (-Mh c1) - (e, d_x hat_a) = 0
-    # Rrot + (-My c0) + (Mx c1) + Er e = 0      (R0 = R1 = 0 already)
-    A = sp.bmat([[-Mh, Z, Dy], [Z, -Mh, -Dx], [-My, Mx, Er]], format="csr")
-    idx = np.concatenate([free, nn + free, 2 * nn + free])
-    rhs = np.concatenate([np.zeros(2 * nn), -R_rot])[idx]
-    sol = spla.spsolve(A[idx][:, idx].tocsc(), rhs)
     c0 = np.zeros(nn)
     c1 = np.zeros(nn)
     e = np.zeros(nn)
-    c0[free], c1[free], e[free] = np.split(sol, 3)
+    e_mean = 0.0
+    if not (free.size >= 20000 if iterative is None else iterative):
+        # blocks of the 3-field system, unknowns (c0, c1, e), equations (R0, R1, Rrot) = 0
+        Mh = assemble_mat(np.einsum("cq,qn,qm->cnm", w, hv, hv))                      # (hat_b, hat_a)
+        My = assemble_mat(np.einsum("cq,cq,qn,qm->cnm", w, Y, hv, hv))                # (hat_b, hat_a y)
+        Mx = assemble_mat(np.einsum("cq,cq,qn,qm->cnm", w, X, hv, hv))
+        Dy = assemble_mat(np.einsum("cq,cn,qm->cnm", w, ghat[..., 1], hv))            # (hat_b, d_y hat_a)
+        Dx = assemble_mat(np.einsum("cq,cn,qm->cnm", w, ghat[..., 0], hv))
+        # (hat_b, 2 hat_a + x . grad hat_a)
+        Er = assemble_mat(2 * np.einsum("cq,qn,qm->cnm", w, hv, hv)
+                          + np.einsum("cq,cqd,cnd,qm->cnm", w, xq, ghat, hv))
+        Z = sp.csr_matrix((nn, nn))
+        # R0 + (-Mh c0) + (e, d_y hat_a) = 0 ; R1 + (-Mh c1) - (e, d_x hat_a) = 0
+        # Rrot + (-My c0) + (Mx c1) + Er e = 0      (R0 = R1 = 0 already)
+        A = sp.bmat([[-Mh, Z, Dy], [Z, -Mh, -Dx], [-My, Mx, Er]], format="csr")
+        idx = np.concatenate([free, nn + free, 2 * nn + free])
+        rhs = np.concatenate([np.zeros(2 * nn), -R_rot])[idx]
+        sol = spla.spsolve(A[idx][:, idx].tocsc(), rhs)
+        c0[free], c1[free], e[free] = np.split(sol, 3)
+    else:
+        # large meshes (benchmark size): e = sum_b d_b (hat_b - 1/3), cell-wise with zero mean, is
+        # orthogonal to the piecewise constant grad hat_a - the force balances stay untouched
+        # (c0 = c1 = 0) - and changes the moment residual by N d, N_ab = (hat_b - 1/3, 2 hat_a +
+        # x . grad hat_a) = sum_T |T|/12 (3 I - 1 1^T): a graph Laplacian, Jacobi-CG
+        vals = (adet[:, None, None] / 24.0 * (3.0 * np.eye(3) - 1.0)[None]).ravel()
+        rows = np.repeat(cn, 3, axis=1).ravel()
+        cols = np.tile(cn, (1, 3)).ravel()
+        N = sp.csr_matrix((vals, (rows, cols)), shape=(nn, nn))[free][:, free].tocsr()
+        d, info = spla.cg(N, -R_rot[free], rtol=1e-14, atol=0.0, maxiter=20000,
+                          M=sp.diags(1.0 / N.diagonal()))
+        if info != 0:
+            raise RuntimeError("stress compatibilisation: CG did not converge")
+        e[free] = d
+        e_mean = e[cn].mean(axis=1, keepdims=True)
     nodes = np.array([[float(a), float(b)] for a, b in dg.nodes])
     hat_at_nodes = hat.tabulate(nodes)[0]  # [j, n]
     f[0] -= np.einsum("jn,cn->cj", hat_at_nodes, c0[cn])
     f[1] -= np.einsum("jn,cn->cj", hat_at_nodes, c1[cn])
-    e_dg = np.einsum("jn,cn->cj", hat_at_nodes, e[cn])
+    e_dg = np.einsum("jn,cn->cj", hat_at_nodes, e[cn]) - e_mean
     G[0][..., 1] += e_dg
     G[1][..., 0] -= e_dg
     return (np.ascontiguousarray(G.reshape(2, -1)), np.ascontiguousarray(f.reshape(2, -1)))

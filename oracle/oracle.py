@@ -65,19 +65,26 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+_MESH_FIELDS = (("x", np.float64), ("cell_nodes", np.int32), ("cell_facets", np.int32),
+                ("facet_nodes", np.int32), ("facet_cells_offsets", np.int32), ("facet_cells", np.int32),
+                ("node_cells_offsets", np.int32), ("node_cells", np.int32),
+                ("node_facets_offsets", np.int32), ("node_facets", np.int32), ("facet_perm", np.uint8))
+
+
 def _mesh_struct(mesh):
-    keep = [np.ascontiguousarray(mesh.x, dtype=np.float64),
-            np.ascontiguousarray(mesh.cell_nodes, dtype=np.int32),
-            np.ascontiguousarray(mesh.cell_facets, dtype=np.int32),
-            np.ascontiguousarray(mesh.facet_nodes, dtype=np.int32),
-            np.ascontiguousarray(mesh.facet_cells_offsets, dtype=np.int32),
-            np.ascontiguousarray(mesh.facet_cells, dtype=np.int32),
-            np.ascontiguousarray(mesh.node_cells_offsets, dtype=np.int32),
-            np.ascontiguousarray(mesh.node_cells, dtype=np.int32),
-            np.ascontiguousarray(mesh.node_facets_offsets, dtype=np.int32),
-            np.ascontiguousarray(mesh.node_facets, dtype=np.int32),
-            np.ascontiguousarray(mesh.facet_perm, dtype=np.uint8)]
+    """C view of the mesh.  The converted arrays are kept on the mesh object (sampled single-patch
+    calls on a 1M-cell mesh would otherwise convert the index arrays on every call); the cache is
+    dropped when one of the mesh's arrays has been replaced."""
+    key = tuple(id(getattr(mesh, name)) for name, _ in _MESH_FIELDS)
+    cached = getattr(mesh, "_oracle_struct", None)
+    if cached is not None and cached[0] == key:
+        return cached[1], cached[2]
+    keep = [np.ascontiguousarray(getattr(mesh, name), dtype=dt) for name, dt in _MESH_FIELDS]
     s = _Mesh(mesh.nnodes, mesh.ncells, mesh.nfacets, *[_p(a) for a in keep])
+    try:
+        mesh._oracle_struct = (key, s, keep)
+    except AttributeError:
+        pass
     return s, keep
 
 

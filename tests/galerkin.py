@@ -35,8 +35,9 @@ def dofmap(mesh, k):
     return cd, nn + nf * ne + nc * ni
 
 
-def solve_poisson(mesh, k, f_exact, qdeg=None, f_dg=None):
-    """u_h in P_k with u_h = 0 on the boundary; returns (u [ndofs], cell dofmap).
+def solve_poisson(mesh, k, f_exact, qdeg=None, f_dg=None, dirichlet_facets=None):
+    """u_h in P_k with u_h = 0 on the boundary (or on `dirichlet_facets` only, natural homogeneous
+    Neumann condition on the other boundary facets); returns (u [ndofs], cell dofmap).
     f_dg: DG_{k-1} nodal values used INSTEAD of f_exact as right-hand side (for k = 1 the
     equilibration needs the primal problem solved with Pi_0 f, demo_reconstruction.py:504)."""
     el = Lagrange(k)
@@ -61,7 +62,7 @@ def solve_poisson(mesh, k, f_exact, qdeg=None, f_dg=None):
     b = np.zeros(ndofs)
     np.add.at(b, cd.ravel(), fe.ravel())
     # homogeneous Dirichlet: vertex and edge DOFs of the boundary facets
-    bf = mesh.boundary_facets()
+    bf = mesh.boundary_facets() if dirichlet_facets is None else np.asarray(dirichlet_facets)
     fixed = np.zeros(ndofs, dtype=bool)
     fixed[mesh.facet_nodes[bf].ravel()] = True
     for j in range(k - 1):

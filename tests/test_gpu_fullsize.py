@@ -1,0 +1,218 @@
+"""Every BASELINE.json configuration at ITS size on the path that ships (library defaults: tiled
+launch for the flux configurations, slots + weak symmetry for the stress), through the C ABI.
+
+At these sizes the CPU oracle is too slow for a full comparison, so each case checks
+  * the acceptance predicates of the reference's tests (python/test/unit/
+    test_fluxeqlb_conditions.py:24-141, test_stressqlb_conditions.py:21-181): divergence, normal-flux
+    jump / conformity, weak symmetry - size independent;
+  * the oracle on a random SAMPLE of 2 000 patches (node mask on the device, node_range on the CPU);
+  * linearity.
+configs[0] (32 x 32, RT_1, real P1 Galerkin flux) is small: it is compared in full with the committed
+golden vector tests/golden/config0_crossed32_k1_galerkin.npz (tests/golden/make_golden_config0.py).
+configs[4] is an 8-GPU run; its kernel (RT_3) runs here on the whole 8M-triangle mesh on ONE device.
+Tolerances: 1e-11 relative to the largest coefficient against the oracle, 1e-10 relative L2
+divergence residual (fp64)."""
+
+import os
+import types
+
+import numpy as np
+import pytest
+
+from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-11
+NSAMPLE = 2000
+
+
+@pytest.fixture(scope="module")
+def cpp():
+    from dolfinx_eqlb_amd import cpp as c
+    assert c.device_count() >= 1, "GPU tests need a HIP device"
+    return c
+
+
+@pytest.fixture(scope="module")
+def mesh500():
+    from dolfinx_eqlb_amd.mesh import create_unit_square
+    from dolfinx_eqlb_amd.synthetic import facet_types
+    mesh = create_unit_square(500, shuffle_seed=1234)
+    assert mesh.ncells == 1_000_000 and mesh.nnodes == 501_001
+    return mesh, facet_types(mesh)
+
+
+@pytest.fixture(scope="module")
+def poisson500(mesh500):
+    from dolfinx_eqlb_amd.synthetic import make_compatible_data
+    mesh, ft = mesh500
+    G, f = make_compatible_data(mesh, 2, ft)
+    return mesh, ft, G, f
+
+
+def _sample_mask(mesh, seed=0):
+    mask = np.zeros(mesh.nnodes, dtype=np.uint8)
+    mask[np.random.default_rng(seed).choice(mesh.nnodes, NSAMPLE, replace=False)] = 1
+    return mask
+
+
+def test_config0_rt1_galerkin_32x32(cpp):
+    """configs[0]: demo_reconstruction.py set-up (crossed 32 x 32, P1 primal solved with Pi_0 f, RT_1,
+    flux BCs on y = 0, 1) - the committed golden vector, all scatter variants."""
+    from golden_util import load_case
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config0_crossed32_k1_galerkin.npz")
+    mesh, k, ft, G, f, expected = load_case(path)
+    assert (mesh.ncells, mesh.nnodes, k) == (4096, 2113, 1)
+    dm = cpp.DeviceMesh(mesh)
+    for scatter in (-1, 0, 2):
+        eq = cpp.SemiExplicitEquilibrator(dm, k, 1)
+        eq.set_option("scatter", scatter)
+        eq.set_boundary(ft)
+        x = eq.equilibrate_host(G, f)
+        assert np.abs(x - expected).max() <= RTOL * np.abs(expected).max(), scatter
+    res, nrm = chk.divergence_residual(mesh, k, x[0], G[0], f[0])
+    assert res <= 1e-10 * nrm
+    assert chk.boundary_flux_residual(mesh, k, x[0], G[0], np.nonzero(ft[0] == 2)[0]) < 1e-10
+
+
+@pytest.mark.parametrize("scatter", [-1, 2])
+def test_config1_se_rt2_1m(cpp, oracle_mod, poisson500, scatter):
+    """configs[1] on the default (AUTO -> tiled) and the explicitly tiled launch."""
+    mesh, ft, G, f = poisson500
+    k = 2
+    dm = cpp.DeviceMesh(mesh)
+    eq = cpp.SemiExplicitEquilibrator(dm, k, 1)
+    eq.set_option("scatter", scatter)
+    eq.set_boundary(ft)
+    x = eq.equilibrate_host(G[None], f[None])
+    assert eq.tiling_info()["ntiles"] > 2000
+    res, nrm = chk.divergence_residual(mesh, k, x[0], G, f)
+    assert res <= 1e-10 * nrm
+    assert chk.jump_residual(mesh, k, x[0], G) <= 1e-9 * np.abs(x).max()
+    x2 = eq.equilibrate_host(2 * G[None], 2 * f[None])
+    assert np.abs(x2 - 2 * x).max() <= 1e-12 * np.abs(x).max()
+    assert np.array_equal(x, eq.equilibrate_host(G[None], f[None]))  # bitwise reproducible
+    # sampled patches against the oracle, on the same launch type
+    mask = _sample_mask(mesh)
+    eq.set_boundary(ft, node_mask=mask)
+    xs = eq.equilibrate_host(G[None], f[None])
+    ref = np.zeros_like(xs)
+    for node in np.nonzero(mask)[0]:
+        oracle_mod.se_reconstruct(mesh, k, ft, G[None], f[None], flux_hdiv=ref,
+                                  node_range=(int(node), int(node) + 1))
+    assert np.abs(xs - ref).max() <= RTOL * np.abs(ref).max()
+
+
+def test_config2_ev_rt2_1m(cpp, oracle_mod, poisson500):
+    """configs[2]: constrained-minimisation equilibrator, conforming output."""
+    from dolfinx_eqlb_amd.eqlb.conforming import conforming_dofmap, conforming_to_broken
+    mesh, ft, G, f = poisson500
+    k = 2
+    dm = cpp.DeviceMesh(mesh)
+    ev = cpp.ConstrainedMinEquilibrator(dm, k, 1)
+    ev.set_boundary(ft)
+    x = ev.equilibrate_host(G[None], f[None])
+    xb = conforming_to_broken(mesh, k, x[0])
+    res, nrm = chk.divergence_residual(mesh, k, xb, np.zeros_like(G), f)
+    assert res <= 1e-10 * nrm
+    # normal continuity holds by construction of the conforming space; the broken output of the
+    # library must show it too
+    ev.set_option("output", 1)
+    xb2 = ev.equilibrate_host(G[None], f[None])[0]
+    assert np.abs(xb2 - xb).max() <= 1e-12 * np.abs(xb).max()
+    assert chk.jump_residual(mesh, k, xb2, np.zeros_like(G)) <= 1e-9 * np.abs(xb).max()
+    ev.set_option("output", 0)
+    mask = _sample_mask(mesh, 1)
+    ev.set_boundary(ft, node_mask=mask)
+    xs = ev.equilibrate_host(G[None], f[None])
+    cd, nd = conforming_dofmap(mesh, k)
+    ref = np.zeros((1, nd))
+    for node in np.nonzero(mask)[0]:
+        oracle_mod.ev_reconstruct(mesh, k, ft, G[None], f[None], cd, nd, flux_hdiv=ref,
+                                  node_range=(int(node), int(node) + 1))
+    assert np.abs(xs - ref).max() <= RTOL * np.abs(ref).max()
+
+
+def test_config3_stress_rt2_1m(cpp, oracle_mod, mesh500):
+    """configs[3]: two stress rows + weak symmetry, data balanced in force and moment."""
+    from test_oracle_stress import asym_moments
+    from dolfinx_eqlb_amd.synthetic import make_compatible_stress_data
+    mesh, ft1 = mesh500
+    k = 2
+    ft = np.repeat(ft1, 2, axis=0)
+    G, f = make_compatible_stress_data(mesh, k, ft)
+    dm = cpp.DeviceMesh(mesh)
+    eq = cpp.SemiExplicitEquilibrator(dm, k, 2, reconstruct_stress=True)
+    eq.set_boundary(ft)
+    x = eq.equilibrate_host(G, f)
+    scale = np.abs(x).max()
+    for r in range(2):
+        res, nrm = chk.divergence_residual(mesh, k, x[r], G[r], f[r])
+        assert res <= 1e-10 * nrm
+        assert chk.jump_residual(mesh, k, x[r], G[r]) <= 1e-9 * scale
+    # weak symmetry (check_eqlb_conditions.py:476-521): (sigma_01 - sigma_10, hat_a) = 0 for all nodes;
+    # the entries are O(|sigma| h^2), the bound is absolute as in tests/test_gpu_stress.py
+    after = np.abs(asym_moments(mesh, k, x)[1]).max()
+    assert after < 1e-11
+    # without the symmetry step the same data violates it by nine orders of magnitude more
+    eq0 = cpp.SemiExplicitEquilibrator(dm, k, 2)
+    eq0.set_boundary(ft)
+    x0 = eq0.equilibrate_host(G, f)
+    before = np.abs(asym_moments(mesh, k, x0)[1]).max()
+    assert before > 1e-8 and after <= 1e-9 * before
+    del x0, eq0
+    assert np.array_equal(x, eq.equilibrate_host(G, f))
+    mask = _sample_mask(mesh, 2)
+    eq.set_boundary(ft, node_mask=mask)
+    xs = eq.equilibrate_host(G, f)
+    ref = np.zeros_like(xs)
+    for node in np.nonzero(mask)[0]:
+        oracle_mod.se_reconstruct(mesh, k, ft, G, f, flux_hdiv=ref, stress=True,
+                                  node_range=(int(node), int(node) + 1))
+    assert np.abs(xs - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
+def test_config4_kernel_rt3_8m_one_gpu(cpp, oracle_mod):
+    """The RT_3 kernel of configs[4] on the whole 8M-triangle mesh (n = 1414) on ONE device (0.96 GB
+    of output): divergence and jump over ALL cells / facets by the on-device estimator
+    (eqlb_se_estimate, itself checked against the numpy predicates in tests/test_gpu_estimate.py), the
+    numpy predicates on a random sample of cells / facets, sampled patches against the oracle."""
+    from dolfinx_eqlb_amd.mesh import create_unit_square
+    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    k, n = 3, 1414
+    mesh = create_unit_square(n, shuffle_seed=1234)
+    assert mesh.ncells == 7_997_584 and mesh.nnodes == 4_001_621
+    ft = facet_types(mesh)
+    G, f = make_compatible_data(mesh, k, ft)
+    dm = cpp.DeviceMesh(mesh)
+    eq = cpp.SemiExplicitEquilibrator(dm, k, 1)
+    eq.set_boundary(ft)
+    x = eq.equilibrate_host(G[None], f[None])
+    div2, sig2, jump = cpp.estimate(dm, k, x, G[None], f[None])
+    rng = np.random.default_rng(3)
+    # numpy predicates on a sample of 200 000 cells / interior facets
+    sel = np.sort(rng.choice(mesh.ncells, 200_000, replace=False))
+    nrt, nd = k * (k + 2), k * (k + 1) // 2
+    sub = types.SimpleNamespace(x=mesh.x, cell_nodes=mesh.cell_nodes[sel], ncells=sel.size)
+    res, nrm = chk.divergence_residual(sub, k, x[0].reshape(-1, nrt)[sel].ravel(),
+                                       G.reshape(-1, nd * 2)[sel].ravel(), f.reshape(-1, nd)[sel].ravel())
+    assert res <= 1e-10 * nrm
+    # whole mesh on the device: sum_T ||.||^2_T against ||f||^2 extrapolated from the sample
+    assert np.sqrt(div2.sum()) <= 1e-10 * nrm * np.sqrt(mesh.ncells / sel.size)
+    assert np.all(np.isfinite(sig2)) and sig2.min() >= 0.0
+    scale = np.abs(x).max()
+    assert jump.max() <= 1e-9 * scale
+    interior = np.nonzero(np.diff(mesh.facet_cells_offsets) == 2)[0]
+    fs = np.sort(rng.choice(interior, 200_000, replace=False))
+    t0, _ = chk._facet_traces(mesh, k, k - 1, x[0], G, fs, 0)
+    t1, _ = chk._facet_traces(mesh, k, k - 1, x[0], G, fs, 1)
+    assert np.abs(t0 + t1).max() <= 1e-9 * scale
+    del div2, sig2, jump, t0, t1
+    mask = _sample_mask(mesh, 4)
+    eq.set_boundary(ft, node_mask=mask)
+    xs = eq.equilibrate_host(G[None], f[None])
+    ref = np.zeros_like(xs)
+    for node in np.nonzero(mask)[0]:
+        oracle_mod.se_reconstruct(mesh, k, ft, G[None], f[None], flux_hdiv=ref,
+                                  node_range=(int(node), int(node) + 1))
+    assert np.abs(xs - ref).max() <= RTOL * np.abs(ref).max()
