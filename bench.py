@@ -5,23 +5,28 @@
 A step = one eqlb_se_equilibrate call = the reference's timed region, one
 `equilibrate_fluxes()` (python/test/performance/perftest.py:145-147), over all patches of the
 mesh, with the inputs (projected flux, projected RHS) and the output resident in HBM and the
-patch SoA / reference tensors cached in the handle ("warm").
+patch SoA / reference tensors cached in the handle ("warm").  The "cold" figure
+(handle creation + patch construction + one call on host arrays, what the reference pays inside
+its timed region, se/reconstruction.hpp:275-313) is reported beside it.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--n 500] [--k 2]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--n 500] [--k 2] [--stress | --ev]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the unit-square strips of the
-ranks form one [0,N]x[0,1] domain; patches are partitioned by node ownership and the partial
-sums of the ghost-cell RT DOFs are exchanged with the strip neighbours (RCCL send/recv) inside
-the timed step - weak scaling, 1M triangles per GPU.
+--gpus N > 1 without a torch.distributed environment: this process starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD (before anything
+touches the GPU) and relays its output and exit code.  Under torch.distributed.run (one rank per
+GPU): the unit-square strips of the ranks form one [0,N]x[0,1] domain; patches are partitioned by
+node ownership and the partial sums of the ghost-cell RT DOFs are exchanged with the strip
+neighbours (RCCL send/recv) inside the timed step - weak scaling, 1M triangles per GPU.
 
-Rank 0 prints ONE JSON line (contract in the task description) with `roofline` (dominant
-kernel, HIP-event time measured live over the timed region) and `cpu_baseline` (the CPU
-restatement of the reference algorithm, oracle/, timed on this box's host cores).
+Rank 0 prints ONE JSON line (contract in the task description) with `roofline` (dominant kernel,
+HIP-event time measured live over the timed region) and `cpu_baseline` (the CPU restatement of
+the reference algorithm, oracle/, timed on this box's host cores).
 """
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,6 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
+
+HEADLINE_METRIC = "equilibrated patches/s (fp64) on 1M-tri Poisson k=2; L2 flux-divergence residual"
 
 
 def parse():
@@ -42,48 +49,82 @@ def parse():
     ap.add_argument("--scatter", type=int, default=None,
                     help="0 slots + reduction, 1 atomics, 2 tiled (default where available)")
     ap.add_argument("--fused", type=int, default=1, help="all patch-size bins in one launch")
+    ap.add_argument("--accumulate", type=int, default=1,
+                    help="1 (default, reference semantics): flux_hdiv += result; 0: store")
     ap.add_argument("--stress", action="store_true",
                     help="two rows + weak symmetry (BASELINE configs[3]); not the headline")
     ap.add_argument("--ev", action="store_true",
-                    help="constrained-minimisation equilibrator (FluxEqlbEV); not the headline")
+                    help="constrained-minimisation equilibrator (FluxEqlbEV, configs[2]); not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shuffle", type=int, default=None, help="seed for random local vertex order")
     return ap.parse_args()
 
 
+def launch_ranks(args):
+    """--gpus N outside torch.distributed.run: start the N ranks as a child process tree.  Nothing in
+    this process has touched the GPU yet (no torch import, no HIP call)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def compulsory_bytes_per_cell(k, nrhs, ev=False):
-    """8 R [k(k+1) + k(k+1)/2 + k(k+2)] + 24 bytes per cell; EV writes the
-    conforming space instead: 1.5 k facet + k^2-k interior DOFs per cell (136 B/cell at k=2)."""
+    """8 R [k(k+1) + k(k+1)/2 + k(k+2)] + 24 bytes per cell (160 at k = 2, R = 1; 296 for
+    the two stress rows; 288 at k = 3); EV writes the conforming space instead: 1.5 k facet + k^2-k
+    interior DOFs per cell (136 B/cell at k=2)."""
     nout = (1.5 * k + k * k - k) if ev else k * (k + 2)
     return 8 * nrhs * (k * (k + 1) + k * (k + 1) // 2 + nout) + 24
 
 
+def metric_name(args):
+    """BASELINE.json's metric for the headline configuration; the other configurations of
+    BASELINE.json name themselves (same unit, same residual)."""
+    tri = f"{4 * args.n * args.n / 1e6:g}M-tri"
+    if args.stress:
+        return (f"equilibrated patches/s (fp64) on {tri} linear elasticity k={args.k}, weakly symmetric "
+                f"stress (two rows + symmetry step); L2 flux-divergence and weak-symmetry residuals")
+    if args.ev:
+        return (f"equilibrated patches/s (fp64) on {tri} Poisson k={args.k}, FluxEqlbEV "
+                f"constrained minimisation; L2 flux-divergence residual")
+    if args.k == 2 and args.n == 500:
+        return HEADLINE_METRIC
+    return f"equilibrated patches/s (fp64) on {tri} Poisson k={args.k}; L2 flux-divergence residual"
+
+
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
-    from dolfinx_eqlb_amd import cpp
-    from dolfinx_eqlb_amd import distributed as dd
-    from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
-    from dolfinx_eqlb_amd.synthetic import make_compatible_data
-
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start the ranks with "
+                 f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...` "
+                 f"(or run `python bench.py --gpus {args.gpus}` outside torch.distributed.run)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     k, n = args.k, args.n
     nrt, nd = k * (k + 2), k * (k + 1) // 2
 
     # ---- problem setup (not timed, host only): mesh strip of this rank, compatible synthetic data
+    from dolfinx_eqlb_amd import distributed as dd
+    from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
+    from dolfinx_eqlb_amd.synthetic import make_compatible_data, make_compatible_stress_data
     part = dd.StripPartition(n, rank, world, shuffle_seed=args.shuffle)
     mesh = part.mesh
     ft = part.facet_types()
     nrhs = 2 if args.stress else 1
     if args.stress:
+        # force- AND moment-balanced rows (what a P_k Galerkin elasticity solution provides): without
+        # the moment balance the weak-symmetry patch problems are solvable but not symmetric
         ft = np.repeat(ft, 2, axis=0)
-        rows = [make_compatible_data(mesh, k, ft[:1], seed=20241003 + rank + 17 * r) for r in range(2)]
-        G = np.stack([r_[0] for r_ in rows]).ravel()
-        f = np.stack([r_[1] for r_ in rows]).ravel()
+        G2, f2 = make_compatible_stress_data(mesh, k, ft, seed=20241003 + rank)
+        G, f = G2.ravel(), f2.ravel()
     else:
         G, f = make_compatible_data(mesh, k, ft, seed=20241003 + rank)
 
@@ -92,18 +133,31 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stress and not args.ev:
         cpu_all = cpu_baseline_all_cores(mesh, k, ft, G, f)
 
+    import torch
+    import torch.distributed as dist
+
+    from dolfinx_eqlb_amd import cpp
+
     if world > 1:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
+    torch.zeros(1, device=dev)  # HIP context up before the cold timing starts
+    torch.cuda.synchronize()
+
+    # ---- cold path (SURVEY 8d "cold alongside"): mesh upload, handle + patch construction, one call on
+    # host arrays (H2D of G, f, sweep, D2H of the flux) - every step the reference's timed region has
+    t_c0 = time.perf_counter()
     dmesh = cpp.DeviceMesh(mesh)
+    t_c1 = time.perf_counter()
     if args.ev:
         if world > 1 or args.stress:
             raise SystemExit("--ev runs on one GPU without --stress")
         eq = cpp.ConstrainedMinEquilibrator(dmesh, k, nrhs)
         fused = True
+        eq.set_option("accumulate", args.accumulate)
         eq.set_boundary(ft)
         nout = eq.ndofs
     else:
@@ -117,11 +171,20 @@ def main():
         eq.set_option("scatter", args.scatter)
         fused = (bool(args.fused) and args.solver in (None, 1)) or args.scatter == 2
         eq.set_option("fused", int(fused))
+        eq.set_option("accumulate", args.accumulate)
         if world > 1 and args.scatter == 2:
             eq.set_priority_cells(part.send_cells)  # their tiles run first: halo exchange behind the rest
         eq.set_boundary(ft, node_mask=part.node_mask)
         nout = mesh.ncells * nrt
+    t_c2 = time.perf_counter()
+    x_cold = eq.equilibrate_host(G.reshape(nrhs, -1), f.reshape(nrhs, -1))
+    t_c3 = time.perf_counter()
     npatch_local = eq.num_patches
+    cold = {"mesh_upload_ms": (t_c1 - t_c0) * 1e3, "create_set_boundary_ms": (t_c2 - t_c1) * 1e3,
+            "host_call_ms": (t_c3 - t_c2) * 1e3, "cold_ms": (t_c3 - t_c1) * 1e3,
+            "patches_per_s": npatch_local / (t_c3 - t_c1),
+            "note": "cold_ms = handle creation + patch construction (set_boundary) + one call on pageable host "
+                    "arrays; the mesh upload is once per mesh"}
     tiling = eq.tiling_info() if (not args.ev and args.scatter == 2) else None
 
     d_G = torch.from_numpy(G).to(dev)
@@ -142,7 +205,7 @@ def main():
             eq.equilibrate_device_tiles(pG, pf, px, nprio, -1, stream)
             halo.finish(d_x, reqs)
             return
-        eq.equilibrate_device(d_G.data_ptr(), d_f.data_ptr(), d_x.data_ptr(), stream)
+        eq.equilibrate_device(pG, pf, px, stream)
         if halo is not None:
             halo.reduce(d_x)
 
@@ -150,16 +213,28 @@ def main():
         if world > 1:
             dist.barrier()
 
-    # correctness of this very configuration (single sweep into a zeroed vector)
+    # correctness of this very configuration (single sweep into a zeroed vector, device-memory path)
     step()
     torch.cuda.synchronize()
+    eq.check_status(stream)
     x_host = d_x.cpu().numpy().copy()
+    checks = {}
+    if world == 1:
+        # the host-memory call of the cold path and the device-memory call agree bitwise
+        checks["host_call_equals_device_call"] = bool(np.array_equal(x_host, x_cold.ravel()))
+    del x_cold
     res = nrm = None
     if world == 1 and args.ev:
         from dolfinx_eqlb_amd.eqlb.conforming import conforming_to_broken
         res, nrm = chk.divergence_residual(mesh, k, conforming_to_broken(mesh, k, x_host),
                                            np.zeros_like(G), f)
-    elif world == 1 and not args.stress:
+    elif world == 1 and args.stress:
+        xr = x_host.reshape(2, -1)
+        rr = [chk.divergence_residual(mesh, k, xr[r], G.reshape(2, -1)[r], f.reshape(2, -1)[r]) for r in range(2)]
+        res = float(np.sqrt(rr[0][0] ** 2 + rr[1][0] ** 2))
+        nrm = float(np.sqrt(rr[0][1] ** 2 + rr[1][1] ** 2))
+        checks["weak_symmetry_residual_max"] = chk.weak_symmetry_residual(mesh, k, xr)[0]
+    elif world == 1:
         res, nrm = chk.divergence_residual(mesh, k, x_host, G, f)
 
     for _ in range(args.warmup):
@@ -192,43 +267,66 @@ def main():
         npatch_total = int(cnt.item())
     else:
         npatch_total = npatch_local
+    step_dev_ms = ev0.elapsed_time(ev1) / args.steps  # device time of one step on the launch stream
 
     # ---- per-kernel device times: bracket events (single-kernel step) or the library's per-launch
     # HIP events recorded on the launch stream inside the timed loop
+    bytes_sweep = float(compulsory_bytes_per_cell(k, nrhs, args.ev) * part.ncells_owned)
+    if args.ev:  # library default: tiled launch for k <= 2
+        patch_kernel = f"k_se_patch_tiled<K={k},EV>" if k <= 2 else f"k_ev_patch_fused<K={k}>"
+    elif args.scatter == 2:
+        patch_kernel = f"k_se_patch_tiled<K={k}>"
+    elif fused:
+        patch_kernel = f"k_se_patch_fused<K={k}>"
+    else:
+        patch_kernel = None
     if single_kernel:
-        bins_ms = [ev0.elapsed_time(ev1) / args.steps, 0.0, 0.0, 0.0, 0.0]
-        reduce_ms = 0.0
+        kernels_ms = {patch_kernel: step_dev_ms}
         timing_method = "two HIP events around the timed region / steps"
     elif two_phase:
         # per-launch event pairs would serialise the two launches of a step against the halo exchange
-        bins_ms = [0.0] * 5
-        reduce_ms = 0.0
-        timing_method = "not measured at N > 1 (two launches per step overlap the halo exchange); see the N = 1 line"
+        kernels_ms = {"step (two tile-range launches + halo pack / RCCL send-recv / unpack)": step_dev_ms}
+        timing_method = "two HIP events around the timed region / steps (whole step incl. halo exchange)"
     else:
         bins_ms = [eq.last_kernel_ms(b) for b in range(5)]
-        reduce_ms = eq.last_kernel_ms(5)
-        timing_method = "HIP event pair per launch inside the timed region (mean)"
-    eq.set_option("timing", 0)
-    ncells_bin = part.patch_cells_per_bin()  # patch-cells handled by each bin's launch
-    dom = int(np.argmax(bins_ms))
-    total_pc = float(sum(ncells_bin))
-    bytes_sweep = compulsory_bytes_per_cell(k, 1, args.ev) * part.ncells_owned
-    if fused:  # one launch does the whole sweep
-        alg_bytes = float(bytes_sweep)
-        if args.ev:  # library default: tiled launch for k <= 2
-            kname = f"k_se_patch_tiled<K={k},EV>" if k <= 2 else f"k_ev_patch_fused<K={k}>"
+        kernels_ms = {}
+        if fused:
+            kernels_ms[patch_kernel + (f" x{nrhs} rows" if nrhs > 1 else "")] = bins_ms[0]
         else:
-            kname = f"k_se_patch_tiled<K={k}>" if args.scatter == 2 else f"k_se_patch_fused<K={k}>"
-        kernels_ms = {kname: bins_ms[0]}
-    else:      # share of the sweep done by the dominant bin's launch
-        alg_bytes = bytes_sweep * ncells_bin[dom] / total_pc
-        kname = f"k_se_patch<K={k},P={4 << dom}>"
-        kernels_ms = {f"patch_P{4 << b}": bins_ms[b] for b in range(5) if bins_ms[b] > 0}
-    achieved = alg_bytes / (bins_ms[dom] * 1e-3) / 1e9 if bins_ms[dom] > 0 else 0.0
+            kernels_ms.update({f"k_se_patch<K={k},P={4 << b}>": bins_ms[b] for b in range(5) if bins_ms[b] > 0})
+        if args.stress:
+            lean = k == 2  # no flux BCs on the benchmark's stress rows
+            kernels_ms["k_se_weaksym_lean" if lean else f"k_se_weaksym<K={k}>"] = eq.last_kernel_ms(6)
+        red = eq.last_kernel_ms(5)
+        if red > 0:
+            kernels_ms["k_ev_reduce" if args.ev else "k_reduce_slots"] = red
+        if halo is not None:
+            kernels_ms["step incl. halo exchange"] = step_dev_ms
+        timing_method = "HIP event pair per kernel group inside the timed region (mean over the steps)"
+    eq.set_option("timing", 0)
+    kname = max(kernels_ms, key=kernels_ms.get)
+    if single_kernel or two_phase:
+        alg_bytes, t_roof = bytes_sweep, step_dev_ms
+        roof_note = None
+    elif fused or args.stress:
+        # several kernels share the sweep's compulsory bytes (inputs read once, output written once):
+        # the fraction is the whole step's, the kernel named is the longest one
+        alg_bytes = bytes_sweep
+        t_roof = sum(v for kk, v in kernels_ms.items() if not kk.startswith("step"))
+        roof_note = ("multi-kernel step: achieved = compulsory bytes of the whole step / sum of its kernel "
+                     "times; `kernel` is the longest one (all_kernels_ms)")
+    else:      # one launch per bin: share of the sweep done by the dominant bin's launch
+        ncells_bin = part.patch_cells_per_bin()
+        dom = int(np.argmax(bins_ms))
+        alg_bytes = bytes_sweep * ncells_bin[dom] / float(sum(ncells_bin))
+        t_roof = bins_ms[dom]
+        roof_note = None
+    achieved = alg_bytes / (t_roof * 1e-3) / 1e9 if t_roof > 0 else 0.0
     peak = 8000.0
+    pmc = measured_counters(kname) if n == 500 and world == 1 else {}
 
     out = {
-        "metric": "equilibrated patches/s (fp64) on 1M-tri Poisson k=2; L2 flux-divergence residual",
+        "metric": metric_name(args),
         "value": npatch_total * args.steps / elapsed,
         "unit": "patches/s",
         "n_gpus": world,
@@ -241,37 +339,55 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"Poisson {4 * n * n} triangles per GPU (crossed unit square {n}x{n}), "
-                        f"P{k} primal, {'FluxEqlbEV' if args.ev else 'FluxEqlbSE'} RT{k}, "
-                        f"homogeneous Dirichlet, fp64",
+            "workload": (f"{'Linear elasticity' if args.stress else 'Poisson'} {4 * n * n} triangles per GPU "
+                         f"(crossed unit square {n}x{n}), P{k} primal, "
+                         f"{'FluxEqlbEV' if args.ev else 'FluxEqlbSE'} RT{k}"
+                         f"{', two stress rows + weak symmetry' if args.stress else ''}, "
+                         f"homogeneous Dirichlet, fp64"),
+            "headline": metric_name(args) == HEADLINE_METRIC,
             "patches_per_gpu": npatch_local, "cells_per_gpu": int(part.ncells_owned),
             "nrhs": nrhs, "weak_symmetry": bool(args.stress),
             "partition": ("node-ownership strips, halo exchange behind the interior tiles" if two_phase
                           else "node-ownership strips") if world > 1 else "none",
             "solver": eq_solver_name(None if args.ev else args.solver),
             "scatter": ("tiled" if k <= 2 else "slots") if args.ev else eq_scatter_name(args.scatter),
+            "accumulate": bool(args.accumulate),
         },
         "roofline": {
             "bound": "hbm",
             "kernel": kname,
             "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-            "traffic": measured_traffic(kname) if n == 500 and world == 1 else None,
+            "traffic": pmc.get("traffic"),
             "algorithmic_bytes_per_launch": alg_bytes,
-            "kernel_ms": bins_ms[dom],
+            "kernel_ms": kernels_ms[kname],
             "kernel_ms_method": timing_method,
-            "all_kernels_ms": kernels_ms | ({"reduce_slots": reduce_ms} if reduce_ms > 0 else {}),
+            "all_kernels_ms": kernels_ms,
         },
+        "cold": cold,
     }
+    if roof_note:
+        out["roofline"]["note"] = roof_note
+    if pmc.get("insts_valu"):
+        # the binding resource of this kernel is VALU issue + latency, not HBM:
+        # issue floor = wave-level VALU instructions x 4 cycles / (1024 SIMDs x 2.4 GHz)
+        floor_ms = pmc["insts_valu"] * 4.0 / (1024 * 2.4e9) * 1e3
+        out["roofline"]["valu_floor_ms"] = floor_ms
+        out["roofline"]["valu_frac"] = floor_ms / kernels_ms[kname] if kernels_ms[kname] > 0 else None
+        out["roofline"]["valu_source"] = pmc.get("source")
     if tiling is not None:
         out["config"]["tiling"] = tiling
     if res is not None:
         out["div_residual_L2"] = res
         out["rhs_norm_L2"] = nrm
         out["div_residual_rel"] = res / nrm
+    if checks:
+        out["checks"] = checks
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.ev:
         out["cpu_baseline"] = cpu_baseline_ev(mesh, k, ft, G, f)
-    elif rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stress:
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline and args.stress:
+        out["cpu_baseline"] = cpu_baseline_stress(mesh, k, ft, G.reshape(2, -1), f.reshape(2, -1))
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(mesh, k, ft, G, f, npatch_local)
         if cpu_all is not None:
             out["cpu_baseline_all_cores"] = cpu_all
@@ -282,14 +398,18 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json);
-    PMC counters cannot be read from inside the process."""
+def measured_counters(kernel):
+    """Per-launch PMC figures of a kernel from the committed rocprofv3 passes (profiles/traffic.json:
+    HBM bytes = FETCH_SIZE x 2 + WRITE_SIZE, SQ_INSTS_VALU); PMC counters cannot be read from inside
+    the process.  Entries are either a byte count or {"traffic", "insts_valu", "source"}."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-            return json.load(fh).get(kernel)
+            v = json.load(fh).get(kernel)
     except OSError:
-        return None
+        return {}
+    if v is None:
+        return {}
+    return v if isinstance(v, dict) else {"traffic": v}
 
 
 def eq_solver_name(v):
@@ -315,6 +435,26 @@ def cpu_baseline(mesh, k, ft, G, f, npatch):
     return {"value": mesh.nnodes / best, "unit": "patches/s", "cores": 1, "kind": "port",
             "sample": f"all {npatch} patches of the workload (one full sweep), best of 3, "
                       f"{best:.2f} s per sweep",
+            "note": "CPU restatement of the reference algorithm (not the dolfinx_eqlb binary)"}
+
+
+def cpu_baseline_stress(mesh, k, ft, G, f):
+    """The same restatement with the weak-symmetry step (se/solve_patch_weaksym.hpp) on a bounded
+    sample: a contiguous range of nodes of the workload, extended to ~10 s of CPU work."""
+    from oracle import oracle
+    x = np.zeros((2, mesh.ncells * k * (k + 2)))
+    nn = min(mesh.nnodes, 20000)
+    t0 = time.perf_counter()
+    oracle.se_reconstruct(mesh, k, ft, G, f, flux_hdiv=x, node_range=(0, nn), stress=True)
+    dt = time.perf_counter() - t0
+    nn2 = int(min(mesh.nnodes, max(nn, nn * 10.0 / max(dt, 1e-3))))
+    if nn2 > nn:
+        t0 = time.perf_counter()
+        oracle.se_reconstruct(mesh, k, ft, G, f, flux_hdiv=x, node_range=(0, nn2), stress=True)
+        dt = time.perf_counter() - t0
+        nn = nn2
+    return {"value": nn / dt, "unit": "patches/s", "cores": 1, "kind": "port",
+            "sample": f"patches of nodes 0..{nn} of the workload (one pass, two rows + weak symmetry), {dt:.2f} s",
             "note": "CPU restatement of the reference algorithm (not the dolfinx_eqlb binary)"}
 
 

@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = [
     "eqlb_halo_pack", "eqlb_halo_unpack_add", "eqlb_ev_estimate",
     "eqlb_se_check_status", "eqlb_ev_check_status",
     "eqlb_se_set_priority_cells", "eqlb_se_num_priority_tiles", "eqlb_se_equilibrate_tiles",
+    "eqlb_se_equilibrate_lists", "eqlb_ev_equilibrate_lists", "eqlb_se_kornconst",
 ]
 
 _lib = None

@@ -602,7 +602,8 @@ void eqlb_se_destroy(eqlb_se_t* h)
   if (h->ev)
   {
     for (int i = 0; i < eqlb_se::EV_RING * eqlb_se::EV_PER_SET; ++i)
-      (void)hipEventDestroy(h->ev[i]);
+      if (h->ev[i])
+        (void)hipEventDestroy(h->ev[i]);
     delete[] h->ev;
   }
   delete h;
@@ -614,7 +615,12 @@ int eqlb_se_set_option(eqlb_se_t* h, const char* key, int32_t value)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_set_option: null argument");
   if (!strcmp(key, "solver"))
   {
-    if (value != EQLB_SOLVER_LDS_CHOLESKY && value != EQLB_SOLVER_SHUFFLE && value != 9)
+#ifdef EQLB_EXP_SOLVER9 // timing-only variant without the solve (wrong results): experiment builds only
+    const bool exp9 = value == 9;
+#else
+    const bool exp9 = false;
+#endif
+    if (value != EQLB_SOLVER_LDS_CHOLESKY && value != EQLB_SOLVER_SHUFFLE && !exp9)
       return fail(EQLB_ERR_INVALID_ARGUMENT, "unknown solver %d", value);
     h->solver = value;
   }
@@ -631,6 +637,12 @@ int eqlb_se_set_option(eqlb_se_t* h, const char* key, int32_t value)
   {
     h->timing = value;
     h->ev_calls = 0;
+  }
+  else if (!strcmp(key, "accumulate"))
+  {
+    if (value != 0 && value != 1)
+      return fail(EQLB_ERR_INVALID_ARGUMENT, "accumulate must be 0 or 1");
+    h->accumulate = value;
   }
   else if (!strcmp(key, "tile_first"))
   {
@@ -793,15 +805,12 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
   return EQLB_OK;
 }
 
-int eqlb_se_equilibrate_with_kornconst(eqlb_se_t* h, const double* flux_dg, const double* rhs_dg,
-                                       double* flux_hdiv, double* cells_kornconst,
-                                       int32_t memspace, void* stream_)
+int eqlb_se_kornconst(eqlb_se_t* h, double* cells_kornconst, int32_t memspace, void* stream_)
 {
-  if (!cells_kornconst)
+  if (!h || !cells_kornconst)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "Equilibration: Input sizes does not match");
-  const int st = eqlb_se_equilibrate(h, flux_dg, rhs_dg, flux_hdiv, memspace, stream_);
-  if (st)
-    return st;
+  if (!h->boundary_set)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_kornconst: boundary data not set");
   const eqlb::DeviceMesh& m = h->mesh->m;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (!h->d_cks && upload<double>(&h->d_cks, nullptr, (size_t)m.nnodes))
@@ -823,6 +832,18 @@ int eqlb_se_equilibrate_with_kornconst(eqlb_se_t* h, const double* flux_dg, cons
     HIP_TRY(hipStreamSynchronize(stream));
   }
   return EQLB_OK;
+}
+
+int eqlb_se_equilibrate_with_kornconst(eqlb_se_t* h, const double* flux_dg, const double* rhs_dg,
+                                       double* flux_hdiv, double* cells_kornconst,
+                                       int32_t memspace, void* stream_)
+{
+  if (!cells_kornconst)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "Equilibration: Input sizes does not match");
+  const int st = eqlb_se_equilibrate(h, flux_dg, rhs_dg, flux_hdiv, memspace, stream_);
+  if (st)
+    return st;
+  return eqlb_se_kornconst(h, cells_kornconst, memspace, stream_);
 }
 
 int64_t eqlb_se_num_patches(const eqlb_se_t* h) { return h ? h->npatch_total : 0; }
@@ -940,17 +961,21 @@ int eqlb_se_export_patches(eqlb_se_t* h, int32_t stride, int32_t* ncells, int32_
   return st ? EQLB_ERR_DEVICE : EQLB_OK;
 }
 
-int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_dg,
-                        double* flux_hdiv, int32_t memspace, void* stream_)
+// The sweep on per-right-hand-side arrays: g[r], f[r], x[r] are the blocks of RHS r (host or device).
+static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const double* const* f_in,
+                             double* const* x_io, int32_t memspace, void* stream_)
 {
-  if (!h || !flux_dg || !rhs_dg || !flux_hdiv)
+  if (!h || !g_in || !f_in || !x_io)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "Equilibration: Input sizes does not match");
+  for (int r = 0; r < h->nrhs; ++r)
+    if (!g_in[r] || !f_in[r] || !x_io[r])
+      return fail(EQLB_ERR_INVALID_ARGUMENT, "Equilibration: Input sizes does not match");
   if (!h->boundary_set)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_equilibrate: boundary data not set");
   const eqlb::DeviceMesh& m = h->mesh->m;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  const size_t n_g = (size_t)h->nrhs * m.ncells * h->nd * 2;
-  const size_t n_f = (size_t)h->nrhs * m.ncells * h->nd;
+  const size_t s_g = (size_t)m.ncells * h->nd * 2, s_f = (size_t)m.ncells * h->nd; // block sizes
+  const size_t n_g = (size_t)h->nrhs * s_g, n_f = (size_t)h->nrhs * s_f;
   // EQLB_SCATTER_AUTO: the tiled launch where it applies and is the fastest (k <= 2, plain flux
   // equilibration, shuffle solver), else slots + reduction
   int scatter_eff = h->scatter;
@@ -959,15 +984,17 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
                       ? EQLB_SCATTER_TILED
                       : EQLB_SCATTER_SLOTS;
   h->scatter_last = scatter_eff;
-  const size_t n_slot = (size_t)h->nrhs * m.ncells * h->nrt;
+  const size_t s_slot = (size_t)m.ncells * h->nrt, n_slot = (size_t)h->nrhs * s_slot;
   // EV mode writes conforming DOFs unless the broken layout is requested
   const bool ev_conf = h->mode == 1 && h->ev_output == 0;
-  const size_t n_x = ev_conf ? (size_t)h->nrhs * h->ev_ndofs : n_slot;
+  const size_t s_x = ev_conf ? (size_t)h->ev_ndofs : s_slot, n_x = (size_t)h->nrhs * s_x;
+  if (!h->accumulate && scatter_eff == EQLB_SCATTER_ATOMIC)
+    return fail(EQLB_ERR_UNSUPPORTED, "\"accumulate\" = 0 is not available with the atomic scatter");
   if (h->mode == 1 && (scatter_eff == EQLB_SCATTER_ATOMIC || h->solver != EQLB_SOLVER_SHUFFLE))
     return fail(EQLB_ERR_UNSUPPORTED, "EV equilibration runs with the shuffle solver (tiled or slot scatter)");
 
-  const double *d_g = flux_dg, *d_f = rhs_dg;
-  double* d_x = flux_hdiv;
+  std::vector<const double*> d_g(g_in, g_in + h->nrhs), d_f(f_in, f_in + h->nrhs);
+  std::vector<double*> d_x(x_io, x_io + h->nrhs);
   if (memspace == EQLB_MEM_HOST)
   {
     if (!h->d_flux_dg)
@@ -976,12 +1003,16 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
           || upload<double>(&h->d_flux_hdiv, nullptr, n_x))
         return EQLB_ERR_DEVICE;
     }
-    HIP_TRY(hipMemcpyAsync(h->d_flux_dg, flux_dg, n_g * sizeof(double), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(h->d_rhs_dg, rhs_dg, n_f * sizeof(double), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(h->d_flux_hdiv, flux_hdiv, n_x * sizeof(double), hipMemcpyHostToDevice, stream));
-    d_g = h->d_flux_dg;
-    d_f = h->d_rhs_dg;
-    d_x = h->d_flux_hdiv;
+    for (int r = 0; r < h->nrhs; ++r)
+    {
+      HIP_TRY(hipMemcpyAsync(h->d_flux_dg + r * s_g, g_in[r], s_g * sizeof(double), hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipMemcpyAsync(h->d_rhs_dg + r * s_f, f_in[r], s_f * sizeof(double), hipMemcpyHostToDevice, stream));
+      if (h->accumulate)
+        HIP_TRY(hipMemcpyAsync(h->d_flux_hdiv + r * s_x, x_io[r], s_x * sizeof(double), hipMemcpyHostToDevice, stream));
+      d_g[r] = h->d_flux_dg + r * s_g;
+      d_f[r] = h->d_rhs_dg + r * s_f;
+      d_x[r] = h->d_flux_hdiv + r * s_x;
+    }
   }
   else if (memspace != EQLB_MEM_DEVICE)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_equilibrate: unknown memory space");
@@ -996,9 +1027,18 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
   hipEvent_t* evs = nullptr;
   if (h->timing)
   {
+    if (h->ev && !h->ev[eqlb_se::EV_RING * eqlb_se::EV_PER_SET - 1])
+    {
+      // an earlier hipEventCreate failed half way: start over
+      for (int i = 0; i < eqlb_se::EV_RING * eqlb_se::EV_PER_SET; ++i)
+        if (h->ev[i])
+          (void)hipEventDestroy(h->ev[i]);
+      delete[] h->ev;
+      h->ev = nullptr;
+    }
     if (!h->ev)
     {
-      h->ev = new hipEvent_t[eqlb_se::EV_RING * eqlb_se::EV_PER_SET];
+      h->ev = new hipEvent_t[eqlb_se::EV_RING * eqlb_se::EV_PER_SET](); // null until created
       for (int i = 0; i < eqlb_se::EV_RING * eqlb_se::EV_PER_SET; ++i)
         HIP_TRY(hipEventCreate(&h->ev[i]));
     }
@@ -1012,14 +1052,29 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
   a.pn = h->pn;
   a.pflag = h->pflag;
   a.tables = h->tables;
-  a.flux_dg = d_g;
-  a.rhs_dg = d_f;
   a.bvals = h->bvals;
-  a.out = (scatter_eff == EQLB_SCATTER_SLOTS) ? h->slots : d_x;
   a.status = h->status;
   a.npatch_total = h->npatch_total;
   a.ncells = m.ncells;
   a.nrhs = h->nrhs;
+  // data of right-hand side r: the kernels address block rhs_in of flux_dg / rhs_dg and block rhs_out
+  // of out; the caller's arrays arrive block by block, the slot buffer is one array
+  auto select_rhs = [&](int r) {
+    a.rhs = r;
+    a.flux_dg = d_g[r];
+    a.rhs_dg = d_f[r];
+    a.rhs_in = 0;
+    if (scatter_eff == EQLB_SCATTER_SLOTS)
+    {
+      a.out = h->slots;
+      a.rhs_out = r;
+    }
+    else
+    {
+      a.out = d_x[r];
+      a.rhs_out = 0;
+    }
+  };
 
   const bool tiled = scatter_eff == EQLB_SCATTER_TILED;
   if (tiled)
@@ -1033,16 +1088,15 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
                                                : std::min(h->tile_count, h->ntiles - h->tile_first);
     eqlb::TileArgs ta{h->t_tiles, h->t_tile_cells, tcount, h->tile_tc,
                       ev_conf ? h->t_facet_owner : nullptr, h->ev_cell_dofs, h->ev_ndofs, m.nfacets,
-                      h->tile_first};
+                      h->tile_first, h->accumulate};
     a.slot_cell = h->t_slot_cell;
     a.slot_info = h->t_slot_info;
     a.pn = h->t_pn;
     a.pflag = h->t_pflag;
     a.npatch_total = h->t_npatch;
-    a.out = d_x;
     for (int r = 0; r < h->nrhs; ++r)
     {
-      a.rhs = r;
+      select_rhs(r);
       if (evs && r == 0)
         HIP_TRY(hipEventRecord(evs[0], stream));
       const int st = eqlb::launch_se_patch_tiled(h->k, h->deg, h->mode, a, ta, stream);
@@ -1068,7 +1122,7 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
     fb.block_start[eqlb::MAX_BINS] = nb;
     for (int r = 0; r < h->nrhs; ++r)
     {
-      a.rhs = r;
+      select_rhs(r);
       if (evs && r == 0)
         HIP_TRY(hipEventRecord(evs[0], stream));
       const int st = (h->mode == 1) ? eqlb::launch_ev_patch_fused(h->k, a, fb, stream)
@@ -1091,7 +1145,7 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
       HIP_TRY(hipEventRecord(evs[2 * b], stream));
     for (int r = 0; r < h->nrhs; ++r)
     {
-      a.rhs = r;
+      select_rhs(r);
       const int st = eqlb::launch_se_patch(h->k, h->deg, h->bins[b].P, h->solver, scatter_eff, a, stream);
       if (st)
         return fail(st, "patch kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
@@ -1102,9 +1156,13 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
   if (h->stress)
   {
     // weak symmetry of rows 0, 1 on the patch-local stresses held in the slots
-    // (se/reconstruction.hpp:237-270; grouped boundary patches :170-234 are not implemented)
+    // (se/reconstruction.hpp:237-270; the grouped boundary patches of :170-234 are flagged by the
+    // patch builder: PFLAG_WS_SKIP / PFLAG_WS_GROUP)
     if (scatter_eff != EQLB_SCATTER_SLOTS)
       return fail(EQLB_ERR_UNSUPPORTED, "stress equilibration needs the slot scatter");
+    if (evs)
+      HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS + 2], stream));
+    select_rhs(0); // the kernel works on the slot rows of RHS 0 and 1
     for (int b = 0; b < eqlb::MAX_BINS; ++b)
     {
       if (h->bins[b].npatch == 0)
@@ -1116,15 +1174,26 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
       if (st)
         return fail(st, "weak-symmetry kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
     }
+    if (evs)
+      HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS + 3], stream));
   }
   if (scatter_eff == EQLB_SCATTER_SLOTS)
   {
     if (evs)
       HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS], stream));
-    if (ev_conf)
-      eqlb::launch_ev_reduce(m, h->k, h->nrhs, h->ev_cell_dofs, h->ev_ndofs, h->slots, d_x, stream);
-    else if (eqlb::launch_reduce_slots(h->nrt, m.ncells, h->nrhs, h->slots, d_x, stream))
-      return fail(EQLB_ERR_UNSUPPORTED, "slot reduction for %d DOFs per cell is not in this build", h->nrt);
+    // blocks that lie behind one another (one array, the usual case) are reduced by one launch
+    bool contiguous = true;
+    for (int r = 1; r < h->nrhs; ++r)
+      contiguous = contiguous && d_x[r] == d_x[0] + r * s_x;
+    const int nlaunch = contiguous ? 1 : h->nrhs, per = contiguous ? h->nrhs : 1;
+    for (int l = 0; l < nlaunch; ++l)
+    {
+      const double* sl = h->slots + (size_t)l * s_slot * 3;
+      if (ev_conf)
+        eqlb::launch_ev_reduce(m, h->k, per, h->ev_cell_dofs, h->ev_ndofs, sl, d_x[l], h->accumulate, stream);
+      else if (eqlb::launch_reduce_slots(h->nrt, m.ncells, per, sl, d_x[l], h->accumulate, stream))
+        return fail(EQLB_ERR_UNSUPPORTED, "slot reduction for %d DOFs per cell is not in this build", h->nrt);
+    }
     if (evs)
       HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS + 1], stream));
   }
@@ -1134,7 +1203,8 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
 
   if (memspace == EQLB_MEM_HOST)
   {
-    HIP_TRY(hipMemcpyAsync(flux_hdiv, d_x, n_x * sizeof(double), hipMemcpyDeviceToHost, stream));
+    for (int r = 0; r < h->nrhs; ++r)
+      HIP_TRY(hipMemcpyAsync(x_io[r], d_x[r], s_x * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     int32_t status = 0;
     HIP_TRY(hipMemcpy(&status, h->status, sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1145,6 +1215,31 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
     }
   }
   return EQLB_OK;
+}
+
+int eqlb_se_equilibrate_lists(eqlb_se_t* h, const double* const* flux_dg, const double* const* rhs_dg,
+                              double* const* flux_hdiv, int32_t memspace, void* stream)
+{
+  return equilibrate_lists(h, flux_dg, rhs_dg, flux_hdiv, memspace, stream);
+}
+
+int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_dg,
+                        double* flux_hdiv, int32_t memspace, void* stream_)
+{
+  if (!h || !flux_dg || !rhs_dg || !flux_hdiv)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "Equilibration: Input sizes does not match");
+  const eqlb::DeviceMesh& m = h->mesh->m;
+  const size_t s_g = (size_t)m.ncells * h->nd * 2, s_f = (size_t)m.ncells * h->nd;
+  const size_t s_x = (h->mode == 1 && h->ev_output == 0) ? (size_t)h->ev_ndofs : (size_t)m.ncells * h->nrt;
+  std::vector<const double*> g(h->nrhs), f(h->nrhs);
+  std::vector<double*> x(h->nrhs);
+  for (int r = 0; r < h->nrhs; ++r)
+  {
+    g[r] = flux_dg + r * s_g;
+    f[r] = rhs_dg + r * s_f;
+    x[r] = flux_hdiv + r * s_x;
+  }
+  return equilibrate_lists(h, g.data(), f.data(), x.data(), memspace, stream_);
 }
 
 int eqlb_se_check_status(eqlb_se_t* h, void* stream_)
@@ -1166,10 +1261,12 @@ int eqlb_se_check_status(eqlb_se_t* h, void* stream_)
 
 double eqlb_se_last_kernel_ms(const eqlb_se_t* h, int32_t which)
 {
-  // which = b (0..4): patch kernel of bin b (P = 4 << b); 5: slot reduction.
+  // which = b (0..4): patch kernel of bin b (P = 4 << b); 5: slot reduction; 6: weak-symmetry kernels.
   // Average device time per launch over the calls recorded since timing was enabled
   // (at most the last EV_RING calls).  Synchronises with the recorded events.
-  if (!h || !h->ev || h->ev_calls == 0 || which < 0 || which > eqlb::MAX_BINS)
+  if (!h || !h->ev || h->ev_calls == 0 || which < 0 || which > eqlb::MAX_BINS + 1)
+    return 0.0;
+  if (which == eqlb::MAX_BINS + 1 && !h->stress)
     return 0.0;
   const bool fused_run = h->mode == 1 || h->scatter_last == EQLB_SCATTER_TILED
                          || (h->fused && h->solver == EQLB_SOLVER_SHUFFLE);
@@ -1410,7 +1507,7 @@ int eqlb_ev_set_option(eqlb_ev_t* h, const char* key, int32_t value)
     dfree(h->se->d_rhs_dg);
     return EQLB_OK;
   }
-  if (!strcmp(key, "timing") || !strcmp(key, "scatter"))
+  if (!strcmp(key, "timing") || !strcmp(key, "scatter") || !strcmp(key, "accumulate"))
     return eqlb_se_set_option(h->se, key, value);
   return fail(EQLB_ERR_INVALID_ARGUMENT, "unknown option '%s'", key);
 }
@@ -1487,6 +1584,14 @@ int eqlb_ev_equilibrate(eqlb_ev_t* h, const double* flux_dg, const double* rhs_d
   if (!h)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "Equilibration: Input sizes does not match");
   return eqlb_se_equilibrate(h->se, flux_dg, rhs_dg, flux_hdiv, memspace, stream);
+}
+
+int eqlb_ev_equilibrate_lists(eqlb_ev_t* h, const double* const* flux_dg, const double* const* rhs_dg,
+                              double* const* flux_hdiv, int32_t memspace, void* stream)
+{
+  if (!h)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "Equilibration: Input sizes does not match");
+  return equilibrate_lists(h->se, flux_dg, rhs_dg, flux_hdiv, memspace, stream);
 }
 
 int64_t eqlb_ev_num_patches(const eqlb_ev_t* h) { return h ? h->se->npatch_total : 0; }

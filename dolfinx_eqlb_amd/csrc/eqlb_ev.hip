@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256)
 k_ev_reduce(int32_t ncells, int32_t nfacets, int nrhs, const int32_t* cell_facets,
             const uint8_t* facet_perm, const int32_t* facet_cells_off, const int32_t* facet_cells,
             const int32_t* cell_dofs, int64_t ndofs, const double* __restrict__ slots,
-            double* __restrict__ x)
+            double* __restrict__ x, int accumulate)
 {
   constexpr int NRT = K * (K + 2), NI = K * K - K;
   const int64_t per_rhs = (int64_t)nfacets + (int64_t)ncells * NI;
@@ -95,7 +95,10 @@ k_ev_reduce(int32_t ncells, int32_t nfacets, int nrhs, const int32_t* cell_facet
     facet_map<K>(facet_perm[(int64_t)c * 3 + lf] != 0, v, g);
 #pragma unroll
     for (int j = 0; j < K; ++j)
-      xr[conf_dof<K>(cell_dofs, cell_facets, nfacets, c, lf * K + j)] += g[j];
+    {
+      double* px = xr + conf_dof<K>(cell_dofs, cell_facets, nfacets, c, lf * K + j);
+      *px = accumulate ? *px + g[j] : g[j];
+    }
   }
   else if constexpr (NI > 0)
   {
@@ -103,7 +106,9 @@ k_ev_reduce(int32_t ncells, int32_t nfacets, int nrhs, const int32_t* cell_facet
     const int32_t c = (int32_t)(q / NI);
     const int i = (int)(q - (int64_t)c * NI);
     const double* s = sl + (int64_t)c * 3 * NRT + 3 * K + i;
-    xr[conf_dof<K>(cell_dofs, cell_facets, nfacets, c, 3 * K + i)] += (s[0] + s[NRT]) + s[2 * NRT];
+    double* px = xr + conf_dof<K>(cell_dofs, cell_facets, nfacets, c, 3 * K + i);
+    const double v = (s[0] + s[NRT]) + s[2 * NRT];
+    *px = accumulate ? *px + v : v;
   }
 }
 
@@ -125,20 +130,20 @@ void launch_ev_boundary_to_broken(const DeviceMesh& m, int k, int nrhs, const in
 }
 
 void launch_ev_reduce(const DeviceMesh& m, int k, int nrhs, const int32_t* cell_dofs, int64_t ndofs,
-                      const double* slots, double* x, hipStream_t stream)
+                      const double* slots, double* x, int accumulate, hipStream_t stream)
 {
   const int ni = k * k - k;
   const int64_t n = ((int64_t)m.nfacets + (int64_t)m.ncells * ni) * nrhs;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   if (k == 1)
     hipLaunchKernelGGL(k_ev_reduce<1>, grid, block, 0, stream, m.ncells, m.nfacets, nrhs, m.cell_facets,
-                       m.facet_perm, m.facet_cells_off, m.facet_cells, cell_dofs, ndofs, slots, x);
+                       m.facet_perm, m.facet_cells_off, m.facet_cells, cell_dofs, ndofs, slots, x, accumulate);
   else if (k == 2)
     hipLaunchKernelGGL(k_ev_reduce<2>, grid, block, 0, stream, m.ncells, m.nfacets, nrhs, m.cell_facets,
-                       m.facet_perm, m.facet_cells_off, m.facet_cells, cell_dofs, ndofs, slots, x);
+                       m.facet_perm, m.facet_cells_off, m.facet_cells, cell_dofs, ndofs, slots, x, accumulate);
   else
     hipLaunchKernelGGL(k_ev_reduce<3>, grid, block, 0, stream, m.ncells, m.nfacets, nrhs, m.cell_facets,
-                       m.facet_perm, m.facet_cells_off, m.facet_cells, cell_dofs, ndofs, slots, x);
+                       m.facet_perm, m.facet_cells_off, m.facet_cells, cell_dofs, ndofs, slots, x, accumulate);
 }
 
 // ---- halo rows of the multi-GPU decomposition -----------------------------------------------------

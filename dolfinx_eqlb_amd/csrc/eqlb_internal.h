@@ -76,7 +76,9 @@ struct SeArgs
   int64_t npatch;             // patches of this bin
   int64_t slot_offset, patch_offset, npatch_total;
   int32_t ncells, nrhs;
-  int32_t rhs;                // index of the right-hand side handled by this launch
+  int32_t rhs;                // index of the right-hand side handled by this launch (flags, bvals)
+  int32_t rhs_in, rhs_out;    // block index of that right-hand side inside flux_dg / rhs_dg and inside out
+                              // (0 when the pointers already address the block: lists of separate arrays)
 };
 
 // bins of a fused launch: blocks [block_start[b], block_start[b+1]) of 256 threads handle bin b
@@ -111,6 +113,7 @@ struct TileArgs
   int64_t ndofs;
   int32_t nfacets;
   int32_t tile_first; // this launch handles the tiles [tile_first, tile_first + ntiles)
+  int32_t accumulate; // 1: flux_hdiv += result (reference semantics), 0: flux_hdiv = result (no read of the old values)
 };
 
 struct BuildArgs
@@ -167,8 +170,8 @@ void launch_ev_boundary_to_broken(const DeviceMesh& m, int k, int nrhs, const in
                                   int64_t ndofs, const double* bv_conf, double* bv_broken,
                                   hipStream_t stream);
 void launch_ev_reduce(const DeviceMesh& m, int k, int nrhs, const int32_t* cell_dofs, int64_t ndofs,
-                      const double* slots, double* x, hipStream_t stream);
-int launch_reduce_slots(int nrt, int32_t ncells, int32_t nrhs, const double* slots, double* x,
+                      const double* slots, double* x, int accumulate, hipStream_t stream);
+int launch_reduce_slots(int nrt, int32_t ncells, int32_t nrhs, const double* slots, double* x, int accumulate,
                         hipStream_t stream);
 int projection_matrix_host(int degree, int nq, const double* pts, const double* wts,
                            std::vector<double>& Pm);
@@ -205,6 +208,7 @@ struct eqlb_se
   int k = 0, deg = 0, nrhs = 0, stress = 0;
   int nrt = 0, nd = 0;
   int solver = EQLB_SOLVER_SHUFFLE, scatter = EQLB_SCATTER_AUTO, timing = 0, fused = 1;
+  int accumulate = 1;               // option "accumulate": 0 stores the result instead of adding it
   int scatter_last = EQLB_SCATTER_SLOTS; // scatter mode the last equilibrate call resolved to
   int mode = 0;                     // 1: constrained-minimisation (EV) patch problems
   int ev_output = 0;                // EV: 0 conforming DOFs, 1 broken hierarchic RT_k layout
@@ -244,7 +248,7 @@ struct eqlb_se
   double *d_flux_dg = nullptr, *d_rhs_dg = nullptr, *d_flux_hdiv = nullptr;
   double *d_cks = nullptr, *d_korn = nullptr; // Korn estimate: per node / staging per cell
   // timing ("timing" option): ring of event sets, one set per equilibrate call
-  static constexpr int EV_RING = 64, EV_PER_SET = 2 * eqlb::MAX_BINS + 2;
-  hipEvent_t* ev = nullptr; // [EV_RING][EV_PER_SET]: bin b start/end at 2b, 2b+1; reduce start/end
+  static constexpr int EV_RING = 64, EV_PER_SET = 2 * eqlb::MAX_BINS + 4;
+  hipEvent_t* ev = nullptr; // [EV_RING][EV_PER_SET]: bin b start/end at 2b, 2b+1; reduce start/end; weak symmetry start/end
   int64_t ev_calls = 0;     // calls recorded since timing was (re)enabled
 };

@@ -236,8 +236,8 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   if (active)
   {
     const double2* Jp = reinterpret_cast<const double2*>(a.cellJ + 4 * (int64_t)cell);
-    const double2* gp_ = reinterpret_cast<const double2*>(a.flux_dg + ((int64_t)r * a.ncells + cell) * (ND * 2));
-    const double* fp_ = a.rhs_dg + ((int64_t)r * a.ncells + cell) * ND;
+    const double2* gp_ = reinterpret_cast<const double2*>(a.flux_dg + ((int64_t)a.rhs_in * a.ncells + cell) * (ND * 2));
+    const double* fp_ = a.rhs_dg + ((int64_t)a.rhs_in * a.ncells + cell) * ND;
     const double2 j0 = Jp[0], j1 = Jp[1];
 #pragma unroll
     for (int i = 0; i < ND; ++i)
@@ -659,6 +659,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       const double sa = group_sum_d<P>(Te[0][0], gbase, sub), sl = group_sum_d<P>(Le[0], gbase, sub);
       ul[0] = (d_fixed || !pvalid) ? 0.0 : sl / sa;
     }
+#ifdef EQLB_EXP_SOLVER9
     else if constexpr (SOLVER == 9)
     {
       // timing-only build (results are wrong): no solve, to price the solver
@@ -666,6 +667,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       for (int h = 0; h < NH; ++h)
         ul[h] = Le[h] + Te[h][0];
     }
+#endif
     else if constexpr (SOLVER == 0)
     {
       double* Ag = sA + (tid / P) * Z::LDS_GROUP;
@@ -1440,7 +1442,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 #ifdef EQLB_EXP_SLOTROW // timing experiment (wrong results): rows of consecutive lanes are contiguous
         double* o = a.out + (slot % ((int64_t)a.ncells * 3)) * NRT;
 #else
-        double* o = a.out + (((int64_t)r * a.ncells + cell) * 3 + ln) * NRT;
+        double* o = a.out + (((int64_t)a.rhs_out * a.ncells + cell) * 3 + ln) * NRT;
 #endif
 #pragma unroll
         for (int e = 0; e < NRT; ++e)
@@ -1448,7 +1450,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       }
       else
       {
-        double* o = a.out + ((int64_t)r * a.ncells + cell) * NRT;
+        double* o = a.out + ((int64_t)a.rhs_out * a.ncells + cell) * NRT;
 #pragma unroll
         for (int e = 0; e < NRT; ++e)
           unsafeAtomicAdd(o + e, cout[e]);
@@ -1744,7 +1746,7 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
   const bool conforming = MODE == 1 && ta.facet_owner != nullptr;
   // flush operands of the broken layout: the old values of flux_hdiv are fetched BEFORE the barrier
   // (only this tile writes them), so that the two dependent loads hide behind the waves still solving
-  double* x = a0.out + (int64_t)a0.rhs * a0.ncells * NRT;
+  double* x = a0.out + (int64_t)a0.rhs_out * a0.ncells * NRT;
   // (two consecutive DOFs per thread where the row length is even: 16-byte loads and stores)
   constexpr int VW = (NRT % 2 == 0) ? 2 : 1;
   constexpr int NIT = (TCMAX * NRT / VW + TILE_THREADS - 1) / TILE_THREADS;
@@ -1767,6 +1769,11 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
       xv[it][0] = xv[it][VW - 1] = 0.0;
       continue;
 #endif
+      if (!ta.accumulate) // store instead of add: the old values are not read (wave-uniform)
+      {
+        xv[it][0] = xv[it][VW - 1] = 0.0;
+        continue;
+      }
       if constexpr (VW == 2)
       {
 #if EQLB_FLUSH_NT
@@ -1789,7 +1796,7 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
     // conforming DOFs (ev/solve_patch.hpp:223-227): facet DOFs by the first cell of the facet,
     // mapped to the global facet frame (T_f = -I / B), interior DOFs by their cell
     constexpr int NI = K * K - K;
-    double* xc = a0.out + (int64_t)a0.rhs * ta.ndofs;
+    double* xc = a0.out + (int64_t)a0.rhs_out * ta.ndofs;
     const int32_t* own = ta.facet_owner + (int64_t)tile * TC * 3;
     for (int e = threadIdx.x; e < TC * 3; e += TILE_THREADS)
     {
@@ -1812,7 +1819,10 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
           g += (rev ? bcoef(j, i) : ((i == j) ? -1.0 : 0.0)) * v[i];
         const int64_t dof = ta.cell_dofs ? (int64_t)ta.cell_dofs[(int64_t)cell * NRT + lf * K + j]
                                          : (int64_t)fct * K + j;
-        xc[dof] += g;
+        if (ta.accumulate)
+          xc[dof] += g;
+        else
+          xc[dof] = g;
       }
     }
     if constexpr (NI > 0)
@@ -1824,7 +1834,11 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
           continue;
         const int64_t dof = ta.cell_dofs ? (int64_t)ta.cell_dofs[(int64_t)cell * NRT + 3 * K + i]
                                          : (int64_t)ta.nfacets * K + (int64_t)cell * NI + i;
-        xc[dof] += packed_sum<K, NPK>(sSlots + (int64_t)cl * 3 * NPK, 3 * K + i);
+        const double v = packed_sum<K, NPK>(sSlots + (int64_t)cl * 3 * NPK, 3 * K + i);
+        if (ta.accumulate)
+          xc[dof] += v;
+        else
+          xc[dof] = v;
       }
     return;
   }
@@ -1906,7 +1920,7 @@ int launch_se_patch_tiled(int k, int deg, int mode, const SeArgs& a, const TileA
 // flux_hdiv[r][cell][i] += slot0 + slot1 + slot2  (fixed order -> bitwise reproducible)
 template <int NRT>
 __global__ void __launch_bounds__(256)
-k_reduce_slots(int64_t ntotal, const double* __restrict__ slots, double* __restrict__ x)
+k_reduce_slots(int64_t ntotal, const double* __restrict__ slots, double* __restrict__ x, int accumulate)
 {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= ntotal)
@@ -1914,23 +1928,24 @@ k_reduce_slots(int64_t ntotal, const double* __restrict__ slots, double* __restr
   const int64_t c = e / NRT;
   const int i = (int)(e - c * NRT);
   const double* s = slots + c * 3 * NRT + i;
-  x[e] += (s[0] + s[NRT]) + s[2 * NRT];
+  const double v = (s[0] + s[NRT]) + s[2 * NRT];
+  x[e] = accumulate ? x[e] + v : v;
 }
 
-int launch_reduce_slots(int nrt, int32_t ncells, int32_t nrhs, const double* slots, double* x,
+int launch_reduce_slots(int nrt, int32_t ncells, int32_t nrhs, const double* slots, double* x, int accumulate,
                         hipStream_t stream)
 {
   const int64_t ntotal = (int64_t)nrhs * ncells * nrt;
   const int block = 256;
   const int64_t grid = (ntotal + block - 1) / block;
   if (nrt == 3)
-    hipLaunchKernelGGL(k_reduce_slots<3>, dim3(grid), dim3(block), 0, stream, ntotal, slots, x);
+    hipLaunchKernelGGL(k_reduce_slots<3>, dim3(grid), dim3(block), 0, stream, ntotal, slots, x, accumulate);
   else if (nrt == 8)
-    hipLaunchKernelGGL(k_reduce_slots<8>, dim3(grid), dim3(block), 0, stream, ntotal, slots, x);
+    hipLaunchKernelGGL(k_reduce_slots<8>, dim3(grid), dim3(block), 0, stream, ntotal, slots, x, accumulate);
   else if (nrt == 15)
-    hipLaunchKernelGGL(k_reduce_slots<15>, dim3(grid), dim3(block), 0, stream, ntotal, slots, x);
+    hipLaunchKernelGGL(k_reduce_slots<15>, dim3(grid), dim3(block), 0, stream, ntotal, slots, x, accumulate);
   else if (nrt == 24)
-    hipLaunchKernelGGL(k_reduce_slots<24>, dim3(grid), dim3(block), 0, stream, ntotal, slots, x);
+    hipLaunchKernelGGL(k_reduce_slots<24>, dim3(grid), dim3(block), 0, stream, ntotal, slots, x, accumulate);
   else
     return EQLB_ERR_UNSUPPORTED;
   return 0;
@@ -1983,8 +1998,10 @@ static int launch_p(int P, const SeArgs& a, hipStream_t stream)
 template <int K, int DEG>
 static int launch_kd(int P, int solver, int scatter, const SeArgs& a, hipStream_t stream)
 {
+#ifdef EQLB_EXP_SOLVER9
   if (solver == 9)
     return launch_p<K, DEG, 9, 0>(P, a, stream);
+#endif
   if (solver == EQLB_SOLVER_SHUFFLE)
   {
     if (scatter == EQLB_SCATTER_SLOTS)

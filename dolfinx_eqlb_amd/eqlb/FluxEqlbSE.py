@@ -2,19 +2,19 @@
 `FluxEqlbSE` (python/dolfinx_eqlb/eqlb/FluxEqlbSE.py:26-198) on flat arrays.
 
 Same constructor arguments, methods and error behaviour; DOLFINx Functions are replaced by
-numpy arrays in the layouts of include/eqlb.h (the DOLFINx adapter a maintainer would write is
-shown in INTEGRATION.md).  All numerical work happens in libeqlb_amd.so on the GPU.
+numpy arrays in the layouts of include/eqlb.h, wrapped (zero copy) into the Function stand-ins of
+the compiled module `dolfinx_eqlb_amd._cpp`, whose functions carry the names and argument order of
+the reference's `dolfinx_eqlb.cpp` (python/dolfinx_eqlb/wrappers.cpp:52-272).  All numerical work
+happens in libeqlb_amd.so on the GPU.
 """
 
 import typing
 
 import numpy as np
 
-from .. import cpp
+from . import _adapter
 from ..mesh import Mesh
-
-
-from .bcs import boundarydata, fluxbc  # noqa: E402,F401  (fluxbc is re-exported from here)
+from .bcs import boundarydata, fluxbc  # noqa: F401  (fluxbc is re-exported from here)
 
 
 class FluxEqlbSE:
@@ -23,18 +23,17 @@ class FluxEqlbSE:
     def __init__(self, degree_flux: int, msh: Mesh, list_rhs: typing.List[np.ndarray],
                  list_proj_flux: typing.List[np.ndarray],
                  equilibrate_stress: typing.Optional[bool] = False,
-                 estimate_korn_constant: typing.Optional[bool] = False,
-                 device_mesh: typing.Optional[cpp.DeviceMesh] = None):
+                 estimate_korn_constant: typing.Optional[bool] = False):
         self.degree_flux = degree_flux
         self.n_fluxes = len(list_rhs)
-        self.equilibrate_stresses = equilibrate_stress
-        self.estimate_korn_constant = estimate_korn_constant
+        self.equilibrate_stresses = bool(equilibrate_stress)
+        self.estimate_korn_constant = bool(estimate_korn_constant)
         self.korn_constants = None
         if len(list_proj_flux) != self.n_fluxes:
             raise RuntimeError("Mismatching inputs!")  # FluxEqlbSE.py:74-75
         self.mesh = msh
-        self.list_rhs = [np.ascontiguousarray(r, dtype=np.float64).ravel() for r in list_rhs]
-        self.list_proj_flux = [np.ascontiguousarray(g, dtype=np.float64).ravel()
+        self.list_rhs = [np.ascontiguousarray(r, dtype=np.float64).ravel().copy() for r in list_rhs]
+        self.list_proj_flux = [np.ascontiguousarray(g, dtype=np.float64).ravel().copy()
                                for g in list_proj_flux]
         nd = self.list_rhs[0].size // msh.ncells
         degree_dg = {1: 0, 3: 1, 6: 2, 10: 3}.get(nd)
@@ -50,14 +49,24 @@ class FluxEqlbSE:
                                    for g in self.list_proj_flux]
             degree_dg = degree_flux - 1
         self.degree_dg = degree_dg
-        self.device_mesh = device_mesh if device_mesh is not None else cpp.DeviceMesh(msh)
-        self._eq = cpp.SemiExplicitEquilibrator(self.device_mesh, degree_flux, self.n_fluxes,
-                                                degree_dg, equilibrate_stress,
-                                                estimate_korn_constant)
+        if equilibrate_stress:  # se/reconstruction.hpp:376-388
+            if self.n_fluxes < 2:
+                raise RuntimeError("Stress equilibration: Specify all rows of stress tensor")
+            if degree_flux < 2:
+                raise RuntimeError("Stress equilibration: RT_k with k>1 required!")
+        # function spaces (FluxEqlbSE.py:94-105): discontinuous hierarchic RT_k, DG_{k-1} (x 2)
+        self.V_flux = _adapter.flux_space(msh, degree_flux, True)
+        self.V_flux_dg = _adapter.dg_space(msh, degree_dg, 2)
+        self.V_rhs = _adapter.dg_space(msh, degree_dg, 1)
         ndofs = degree_flux * (degree_flux + 2)
         self.list_flux = np.zeros((self.n_fluxes, msh.ncells * ndofs))
+        self._f_flux = [_adapter.function(self.V_flux, self.list_flux[i]) for i in range(self.n_fluxes)]
+        self._f_proj = [_adapter.function(self.V_flux_dg, g) for g in self.list_proj_flux]
+        self._f_rhs = [_adapter.function(self.V_rhs, r) for r in self.list_rhs]
+        self._f_korn = None
         if estimate_korn_constant:
             self.korn_constants = np.zeros(msh.ncells)  # DG0 function of the reference
+            self._f_korn = _adapter.function(_adapter.dg_space(msh, 0, 1), self.korn_constants)
         self.boundary_data = None
 
     def set_boundary_conditions(self, list_bfct_prime: typing.List[np.ndarray],
@@ -68,27 +77,24 @@ class FluxEqlbSE:
             raise RuntimeError("Mismatching inputs!")
         # boundary functions of the discontinuous hierarchic RT_k space (FluxEqlbSE.py:134-145)
         self.list_bfunctions = [np.zeros(self.list_flux.shape[1]) for _ in range(self.n_fluxes)]
-        bd = boundarydata(list_bcs_flux, self.list_bfunctions, (self.mesh, self.degree_flux), True,
-                          list_bfct_prime, self.equilibrate_stresses)
-        self.facet_type = bd.facet_type
-        self.boundary_values = bd.boundary_values
-        self._eq.set_boundary(bd.facet_type, boundary_values=bd.boundary_values)
-        self.boundary_data = self._eq
+        self.boundary_data = boundarydata(list_bcs_flux, self.list_bfunctions, self.V_flux, True,
+                                          list_bfct_prime, self.equilibrate_stresses)
+        self.facet_type = self.boundary_data.facet_type
 
     def equilibrate_fluxes(self):
         """Equilibrate the fluxes (accumulates into list_flux like the reference)."""
         if self.boundary_data is None:
             raise RuntimeError("Boundary conditions have not been set")
+        c = _adapter.module()
         if self.estimate_korn_constant:
             # reconstruct_fluxes_semiexplt_with_kornconst + sqrt (FluxEqlbSE.py:152-166)
-            self._eq.equilibrate_host_with_kornconst(np.stack(self.list_proj_flux),
-                                                     np.stack(self.list_rhs), self.list_flux,
-                                                     self.korn_constants)
+            c.reconstruct_fluxes_semiexplt_with_kornconst(self._f_flux, self._f_proj, self._f_rhs,
+                                                          self.boundary_data, self.equilibrate_stresses,
+                                                          self._f_korn)
             self.korn_constants[:] = np.sqrt(self.korn_constants)
         else:
-            cpp.reconstruct_fluxes_semiexplt(self.list_flux, np.stack(self.list_proj_flux),
-                                             np.stack(self.list_rhs), self.boundary_data,
-                                             self.equilibrate_stresses)
+            c.reconstruct_fluxes_semiexplt(self._f_flux, self._f_proj, self._f_rhs, self.boundary_data,
+                                           self.equilibrate_stresses)
 
     def get_reconstructed_fluxes(self, subproblem: int):
         """(corrector in discontinuous hierarchic RT_k, projected flux in DG_{k-1}^2): the

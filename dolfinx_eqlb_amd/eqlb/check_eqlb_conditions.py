@@ -192,3 +192,27 @@ def hdiv_seminorm_error(mesh, k, sigma_eq, flux_dg, rhs_exact, degree_dg=None):
     fq = rhs_exact(xq[..., 0], xq[..., 1])
     w = qw[None, :] * np.abs(detJ)[:, None]
     return float(np.sqrt(np.sum(w * (div_sig + div_G - fq) ** 2)))
+
+
+def weak_symmetry_residual(mesh, k, sigma):
+    """Assembled vector L_a = (sigma_01 - sigma_10, hat_a) over the P1 test space for a stress with
+    the rows sigma [2, ncells*k(k+2)] (broken hierarchic RT_k); returns (max_a |L_a|, L).
+    The linear form of check_weak_symmetry_condition, check_eqlb_conditions.py:476-521."""
+    J, detJ, K = cell_geometry(mesh)
+    rt = ert.HierarchicRT(k)
+    qp, qw = make_quadrature_triangle(k + 2)
+    phi = rt.tabulate(qp)
+    hv = Lagrange(1).tabulate(qp)[0]
+    c = np.asarray(sigma).reshape(2, mesh.ncells, rt.ndofs)
+    # physical rows: J phi / detJ; only the components (row 0, y) and (row 1, x) are needed
+    r0y = np.einsum("cj,ci,qij->cq", J[:, 1, :], c[0], phi) / detJ[:, None]
+    r1x = np.einsum("cj,ci,qij->cq", J[:, 0, :], c[1], phi) / detJ[:, None]
+    loc = np.einsum("cq,cq,qn->cn", qw[None] * np.abs(detJ)[:, None], r0y - r1x, hv)
+    L = np.zeros(mesh.nnodes)
+    np.add.at(L, mesh.cell_nodes.ravel(), loc.ravel())
+    return float(np.abs(L).max()), L
+
+
+def check_weak_symmetry_condition(mesh, k, sigma, rtol=1e-5, atol=1e-8) -> bool:
+    """np.allclose(L, 0) as the reference (check_eqlb_conditions.py:517)."""
+    return bool(np.allclose(weak_symmetry_residual(mesh, k, sigma)[1], 0.0, rtol=rtol, atol=atol))

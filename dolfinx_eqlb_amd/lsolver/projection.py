@@ -10,7 +10,6 @@ import typing
 
 import numpy as np
 
-from .. import cpp
 from ..elmtlib.quadrature import make_quadrature_triangle
 from ..eqlb.check_eqlb_conditions import cell_geometry
 
@@ -22,15 +21,22 @@ def quadrature_points_physical(mesh, qpoints):
     return x0[:, None, :] + np.einsum("cij,qj->cqi", J, qpoints)
 
 
-def local_projection(dmesh: "cpp.DeviceMesh", degree: int, data: typing.List[typing.Any], bs: int = 1,
-                     quadrature_degree: typing.Optional[int] = None) -> typing.List[np.ndarray]:
+def local_projection(dmesh, degree: int, data: typing.List[typing.Any], bs: int = 1,
+                     quadrature_degree: typing.Optional[int] = None,
+                     solver: str = "cholesky") -> typing.List[np.ndarray]:
     """Project every entry of `data` into DG_degree (block size bs); returns the DOF arrays
-    [ncells*nd*bs] (cell-major, x[bs*dof+cb]).  data[i]: callable(x, y) or array [ncells, nq, bs]."""
-    mesh = dmesh.mesh
+    [ncells*nd*bs] (cell-major, x[bs*dof+cb]).  data[i]: callable(x, y) or array [ncells, nq, bs].
+    `dmesh`: flat mesh container (or a `cpp.DeviceMesh` of one).  The solve runs through
+    `local_solver_<solver>` of the compiled module (names of python/dolfinx_eqlb/wrappers.cpp:52-80):
+    a = (u, v) on DG_degree, l_i = (f_i, v) given by the point values of f_i."""
+    from ..eqlb import _adapter
+    c = _adapter.module()
+    mesh = getattr(dmesh, "mesh", dmesh)
     qdeg = 2 * degree + 2 if quadrature_degree is None else quadrature_degree
     qp, qw = make_quadrature_triangle(qdeg)
     xq = None
-    vals = []
+    V = _adapter.dg_space(mesh, degree, bs)
+    sols, forms = [], []
     for d in data:
         if callable(d):
             if xq is None:
@@ -38,9 +44,13 @@ def local_projection(dmesh: "cpp.DeviceMesh", degree: int, data: typing.List[typ
             v = np.asarray(d(xq[..., 0], xq[..., 1]), dtype=np.float64)
         else:
             v = np.asarray(d, dtype=np.float64)
-        vals.append(v.reshape(mesh.ncells, qw.size, bs))
-    out = cpp.project_dg(dmesh, degree, qp, qw, np.stack(vals), bs)
-    return [out[i] for i in range(len(data))]
+        if v.size != mesh.ncells * qw.size * bs:
+            raise RuntimeError("Local solver: Input sizes does not match")
+        forms.append(c.Form.from_point_values(qp, qw, np.ascontiguousarray(v.reshape(mesh.ncells, qw.size, bs))))
+        sols.append(c.Function(V))
+    fn = {"cholesky": c.local_solver_cholesky, "lu": c.local_solver_lu, "cg": c.local_solver_cg}[solver]
+    fn(sols, c.Form([]), forms)
+    return [s_.array for s_ in sols]
 
 
 def embed_dg(values, ncells: int, degree_from: int, degree_to: int, bs: int = 1):

@@ -108,7 +108,10 @@ void eqlb_se_destroy(eqlb_se_t* handle);
  * (EQLB_SCATTER_*; default AUTO), "fused" (1: all patch-size bins of the slot path in one launch,
  * default), "timing" (1: record HIP events around the kernels, see eqlb_se_last_kernel_ms),
  * "tile_first" / "tile_count" (range of tiles swept by the next tiled launches, default 0 / -1 = all;
- * see eqlb_se_set_priority_cells). */
+ * see eqlb_se_set_priority_cells), "accumulate" (1, default: flux_hdiv += result as the reference does,
+ * se/solve_patch_semiexplt.hpp:1157-1160, which assumes a zero-initialised output; 0: flux_hdiv = result,
+ * the old values are neither read nor uploaded - every DOF of every cell is written; not with the
+ * atomic scatter). */
 int eqlb_se_set_option(eqlb_se_t* handle, const char* key, int32_t value);
 
 /*
@@ -152,6 +155,13 @@ int eqlb_se_set_boundary(eqlb_se_t* handle, const int8_t* facet_type,
 int eqlb_se_equilibrate(eqlb_se_t* handle, const double* flux_dg, const double* rhs_dg,
                         double* flux_hdiv, int32_t memspace, void* stream);
 
+/* The same call on one array per right-hand side - what the reference's binding receives: lists of
+ * dolfinx Functions (wrappers.cpp:97-115: flux_hdiv, flux_dg, rhs_dg), each with its own vector.
+ * flux_dg[r], rhs_dg[r], flux_hdiv[r] (r < nrhs) are the blocks of eqlb_se_equilibrate; all in the
+ * same memory space. */
+int eqlb_se_equilibrate_lists(eqlb_se_t* handle, const double* const* flux_dg, const double* const* rhs_dg,
+                              double* const* flux_hdiv, int32_t memspace, void* stream);
+
 /*
  * Same as eqlb_se_equilibrate plus the upper bounds of the cells' squared Korn constants:
  * reconstruct_fluxes_semiexplt_with_kornconst (wrappers.cpp:117-137) =
@@ -162,6 +172,10 @@ int eqlb_se_equilibrate(eqlb_se_t* handle, const double* flux_dg, const double* 
 int eqlb_se_equilibrate_with_kornconst(eqlb_se_t* handle, const double* flux_dg,
                                        const double* rhs_dg, double* flux_hdiv,
                                        double* cells_kornconst, int32_t memspace, void* stream);
+
+/* The Korn part of that call alone (cells_kornconst [ncells] += (gdim+1) c_K^2 per patch cell), for
+ * callers that equilibrate through eqlb_se_equilibrate_lists. */
+int eqlb_se_kornconst(eqlb_se_t* handle, double* cells_kornconst, int32_t memspace, void* stream);
 
 /* Number of patches equilibrated per call (nodes selected by node_mask). */
 int64_t eqlb_se_num_patches(const eqlb_se_t* handle);
@@ -230,7 +244,8 @@ int eqlb_se_check_status(eqlb_se_t* handle, void* stream);
  * each kernel (ring of the last 64 calls).  Returns the average device time in ms per launch of
  * kernel `which` over the recorded calls: which = b in 0..4: patch kernel of the bin with
  * P = 4 << b lanes per patch (single-launch paths - tiled and fused - report in slot 0);
- * which = 5: slot-reduction kernel (0 on the tiled path).  Synchronises with the events;
+ * which = 5: slot-reduction kernel (0 on the tiled path); which = 6: the weak-symmetry kernels of a
+ * stress equilibration (all bins together).  Synchronises with the events;
  * 0 if nothing was recorded.  Setting the option again resets the ring. */
 double eqlb_se_last_kernel_ms(const eqlb_se_t* handle, int32_t which);
 
@@ -298,8 +313,8 @@ int eqlb_ev_create(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, eqlb_ev_t** handl
 void eqlb_ev_destroy(eqlb_ev_t* handle);
 
 /* "output": 0 conforming DOFs (default), 1 broken hierarchic RT_k layout [ncells*k(k+2)] as
- * eqlb_se_equilibrate writes it; "timing", "scatter" (EQLB_SCATTER_AUTO / _SLOTS / _TILED): as
- * eqlb_se_set_option. */
+ * eqlb_se_equilibrate writes it; "timing", "scatter" (EQLB_SCATTER_AUTO / _SLOTS / _TILED),
+ * "accumulate": as eqlb_se_set_option. */
 int eqlb_ev_set_option(eqlb_ev_t* handle, const char* key, int32_t value);
 
 /* cell_dofs [ncells][k(k+2)] host array (NULL restores the default numbering), ndofs = size of the
@@ -319,6 +334,9 @@ int eqlb_ev_set_boundary(eqlb_ev_t* handle, const int8_t* facet_type,
  * ev/solve_patch.hpp:223-227. */
 int eqlb_ev_equilibrate(eqlb_ev_t* handle, const double* flux_dg, const double* rhs_dg,
                         double* flux_hdiv, int32_t memspace, void* stream);
+/* one array per right-hand side, as eqlb_se_equilibrate_lists (wrappers.cpp:85-95: list of flux_hdiv) */
+int eqlb_ev_equilibrate_lists(eqlb_ev_t* handle, const double* const* flux_dg, const double* const* rhs_dg,
+                              double* const* flux_hdiv, int32_t memspace, void* stream);
 int64_t eqlb_ev_num_patches(const eqlb_ev_t* handle);
 /* which = 0: patch kernel (all bins in one launch), 5: reduction to the conforming DOFs */
 double eqlb_ev_last_kernel_ms(const eqlb_ev_t* handle, int32_t which);

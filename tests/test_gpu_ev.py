@@ -154,3 +154,17 @@ def test_ev_tiled_is_bitwise_the_slot_path(oracle_mod, k):
     eqp.set_option("scatter", 2)
     eqp.set_boundary(ft)
     assert _close(eqp.equilibrate_host(G, f)[0][perm], ref[0])
+
+
+@pytest.mark.parametrize("k,sc", [(1, 2), (2, 2), (2, 0), (3, 0)])
+def test_ev_accumulate_option(k, sc):
+    """"accumulate" = 0 on the conforming flush (tiled) and on the reduction (slots)."""
+    from dolfinx_eqlb_amd import cpp
+    mesh, ft, G, f = make_case(12, k, "neumann_lt")
+    eq = cpp.ConstrainedMinEquilibrator(cpp.DeviceMesh(mesh), k, 1)
+    eq.set_option("scatter", sc)
+    eq.set_boundary(ft)
+    a = eq.equilibrate_host(G, f)
+    eq.set_option("accumulate", 0)
+    b = eq.equilibrate_host(G, f, np.full_like(a, -3.5))
+    assert np.array_equal(a, b)

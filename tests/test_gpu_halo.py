@@ -174,3 +174,83 @@ def test_two_phase_sweep_with_halo_between(oracle_mod):
         got = xs[r].cpu().numpy().reshape(-1, nrt)[own]
         ref = gref[gcells[r][own]]
         assert np.abs(got - ref).max() <= 1e-10 * np.abs(gref).max()
+
+
+def test_halo_exchange_class_on_device_with_side_stream_transport(oracle_mod, monkeypatch):
+    """HaloExchange.start / finish themselves (not the bare halo kernels) on CUDA tensors: three strips
+    on one device, two accumulating two-phase steps.  RCCL is replaced by a stand-in with the stream
+    semantics of the NCCL backend: batch_isend_irecv enqueues the copies on a SIDE stream that waits
+    for the caller's current stream, wait() makes the current stream wait for the side stream.  That
+    exercises what the gloo tests cannot: the ordering of the ctypes-launched pack / unpack kernels
+    (raw stream handle) against the transport stream, the re-use of the cached P2POp list and of the
+    persistent send / receive buffers across steps, and the clearing of the ghost rows."""
+    import torch
+    import torch.distributed as dist
+    from dolfinx_eqlb_amd import cpp
+    from dolfinx_eqlb_amd import distributed as dd
+    from dolfinx_eqlb_amd.mesh import create_rectangle
+    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    world, n, k, nsteps = 3, 24, 2, 3
+    nrt = k * (k + 2)
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream(device=dev)
+    mailbox = {}  # (src, dst) -> tensor in flight
+
+    class P2POp:  # descriptors only (the real class needs an initialised process group)
+        def __init__(self, op, tensor, peer, *a, **kw):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    class Work:
+        def wait(self):
+            torch.cuda.current_stream().wait_stream(side)
+            return True
+
+    current_rank = [0]
+
+    def batch_isend_irecv(ops):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for op in ops:
+                if op.op is dist.isend:
+                    mailbox[(current_rank[0], op.peer)] = op.tensor.clone()
+                else:
+                    op.tensor.copy_(mailbox.pop((op.peer, current_rank[0])))
+        return [Work() for _ in ops]
+
+    monkeypatch.setattr(dist, "P2POp", P2POp)
+    monkeypatch.setattr(dist, "batch_isend_irecv", batch_isend_irecv)
+
+    gmesh = create_rectangle(world * n, n, 0.0, float(world))
+    gft = facet_types(gmesh)
+    gG, gf = make_compatible_data(gmesh, k, gft, seed=5)
+    gref = oracle_mod.se_reconstruct(gmesh, k, gft, gG[None], gf[None])[0].reshape(gmesh.ncells, nrt)
+    ranks = []
+    for rank in range(world):
+        part = dd.StripPartition(n, rank, world)
+        gi, gj, gt = part.grid_ids
+        gcell = (gj * (world * n) + gi + rank * n) * 4 + gt
+        eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(part.mesh), k, 1)
+        eq.set_priority_cells(part.send_cells)
+        eq.set_boundary(part.facet_types(), node_mask=part.node_mask)
+        ranks.append(dict(part=part, gcell=gcell, eq=eq, halo=dd.HaloExchange(part, nrt, dev, 1),
+                          G=torch.from_numpy(gG.reshape(gmesh.ncells, -1)[gcell].ravel()).to(dev),
+                          f=torch.from_numpy(gf.reshape(gmesh.ncells, -1)[gcell].ravel()).to(dev),
+                          x=torch.zeros(part.mesh.ncells * nrt, dtype=torch.float64, device=dev)))
+    stream = torch.cuda.current_stream().cuda_stream
+    for step in range(nsteps):
+        for rank, r in enumerate(ranks):  # ascending: the send of rank - 1 is in flight when rank receives
+            current_rank[0] = rank
+            eq, x, nprio = r["eq"], r["x"], r["eq"].num_priority_tiles
+            eq.equilibrate_device_tiles(r["G"].data_ptr(), r["f"].data_ptr(), x.data_ptr(), 0, nprio, stream)
+            reqs = r["halo"].start(x)
+            eq.equilibrate_device_tiles(r["G"].data_ptr(), r["f"].data_ptr(), x.data_ptr(), nprio, -1, stream)
+            r["halo"].finish(x, reqs)
+    torch.cuda.synchronize()
+    assert not mailbox
+    for r in ranks:
+        part = r["part"]
+        x = r["x"].cpu().numpy().reshape(part.mesh.ncells, nrt)
+        ref = nsteps * gref[r["gcell"][part.cell_owned]]
+        assert np.abs(x[part.cell_owned] - ref).max() <= 1e-10 * nsteps * np.abs(gref).max()
+        if part.send_cells.size:
+            assert np.all(x[part.send_cells] == 0.0)  # ghost rows cleared after packing

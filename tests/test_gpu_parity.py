@@ -338,3 +338,30 @@ def test_tiling_is_independent_of_the_cell_aspect_ratio(cpp, aspect):
     ti = eq.tiling_info()
     assert ti["ntiles"] == (mesh.ncells + ti["cells_per_tile"] - 1) // ti["cells_per_tile"]
     assert ti["patch_instances"] <= 1.3 * eq.num_patches
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+@pytest.mark.parametrize("scatter", [0, 2])
+def test_accumulate_option_stores_instead_of_adding(cpp, oracle_mod, k, scatter):
+    """"accumulate" = 0: flux_hdiv = result (old content overwritten, never read), bitwise the
+    accumulated result on a zeroed vector; the atomic scatter refuses it."""
+    mesh, ft, G, f = make_case(20, k, "neumann_lt")
+    a, eq = _gpu(cpp, mesh, k, ft, G, f, scatter=scatter)
+    eq.set_option("accumulate", 0)
+    junk = np.full_like(a, 7.25)
+    b = eq.equilibrate_host(G, f, junk)
+    assert np.array_equal(a, b)
+    eq.set_option("accumulate", 1)
+    c = eq.equilibrate_host(G, f, b.copy())
+    assert np.allclose(c, 2 * a, rtol=1e-14, atol=0)
+    eq.set_option("scatter", 1)
+    eq.set_option("accumulate", 0)
+    with pytest.raises(RuntimeError, match="accumulate"):
+        eq.equilibrate_host(G, f)
+
+
+def test_timing_only_solver_is_not_in_the_product_build(cpp):
+    mesh, ft, G, f = make_case(4, 2)
+    eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(mesh), 2, 1)
+    with pytest.raises(RuntimeError, match="unknown solver"):
+        eq.set_option("solver", 9)

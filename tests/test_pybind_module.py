@@ -1,0 +1,285 @@
+"""The compiled module `dolfinx_eqlb_amd._cpp`: names, argument order and error behaviour of the
+reference's pybind11 binding `dolfinx_eqlb.cpp` (python/dolfinx_eqlb/wrappers.cpp:52-272) over the
+C ABI.  CPU part: the module loads and exports the reference's names; GPU part: semi-explicit
+equilibration (with Korn constants, with stress), constrained minimisation, the local solvers and the
+boundary classes are driven through it and compared with the oracle."""
+
+import ctypes
+import inspect
+
+import numpy as np
+import pytest
+
+from cases import BCS, make_case
+
+REFERENCE_NAMES = ["local_solver_lu", "local_solver_cholesky", "local_solver_cg",
+                   "reconstruct_fluxes_minimisation", "reconstruct_fluxes_semiexplt",
+                   "reconstruct_fluxes_semiexplt_with_kornconst", "FluxBC", "BoundaryData"]
+
+
+def test_module_exports_the_reference_names():
+    from dolfinx_eqlb_amd import _cpp
+    for name in REFERENCE_NAMES:
+        assert hasattr(_cpp, name), name
+    # argument names and order of wrappers.cpp:97-137, 85-95, 54-79
+    doc = _cpp.reconstruct_fluxes_semiexplt.__doc__
+    assert "flux_hdiv" in doc and doc.index("flux_hdiv") < doc.index("flux_dg") < doc.index("rhs_dg") \
+        < doc.index("boundary_data") < doc.index("reconstruct_stress")
+    doc = _cpp.reconstruct_fluxes_semiexplt_with_kornconst.__doc__
+    assert doc.index("reconstruct_stress") < doc.index("cells_kornconst")
+    doc = _cpp.reconstruct_fluxes_minimisation.__doc__
+    assert doc.index("a:") < doc.index("l_pen") < doc.index("l:") < doc.index("flux_hdiv") < doc.index("boundary_data")
+    doc = _cpp.local_solver_cholesky.__doc__
+    assert doc.index("solution") < doc.index("a:") < doc.index("l:")
+    doc = _cpp.BoundaryData.__init__.__doc__
+    for a, b in zip(["list_of_bcs", "list_of_boundary_fluxes", "V_flux_hdiv", "rtflux_is_custom",
+                     "quadrature_degree", "list_bfcts_prime"],
+                    ["list_of_boundary_fluxes", "V_flux_hdiv", "rtflux_is_custom", "quadrature_degree",
+                     "list_bfcts_prime", "reconstruct_stress"]):
+        assert doc.index(a) < doc.index(b)
+    doc = _cpp.FluxBC.__init__.__doc__
+    assert "pointer_boundary_kernel" in doc and "nevals_per_fct" in doc and "position_of_coefficients" in doc
+    assert inspect.isdatadescriptor(_cpp.FluxBC.quadrature_degree)
+
+
+def test_facet_rule_is_the_gauss_rule_of_the_front_end():
+    from dolfinx_eqlb_amd import _cpp
+    from dolfinx_eqlb_amd.elmtlib.quadrature import make_quadrature_interval
+    for deg in range(0, 13):
+        s, w = _cpp.facet_quadrature(deg)
+        assert s.size == (deg + 2) // 2
+        for j in range(deg + 1):  # exact for degree `deg` on [0, 1]
+            assert abs(w @ s ** j - 1.0 / (j + 1)) < 1e-14
+    s, w = _cpp.facet_quadrature(6)
+    s2, w2 = make_quadrature_interval(6)
+    if s.size == s2.size:
+        assert np.allclose(s, s2) and np.allclose(w, w2)
+
+
+def test_without_a_device_the_module_raises():
+    from dolfinx_eqlb_amd import _cpp
+    from dolfinx_eqlb_amd.eqlb import _adapter
+    from dolfinx_eqlb_amd.mesh import create_unit_square
+    if _cpp.device_count() > 0:
+        pytest.skip("a device is visible")
+    with pytest.raises(RuntimeError):
+        _adapter.cpp_mesh(create_unit_square(2))
+
+
+# ---- GPU ------------------------------------------------------------------------------------------
+def _spaces(mesh, k):
+    from dolfinx_eqlb_amd.eqlb import _adapter as ad
+    return ad.flux_space(mesh, k, True), ad.dg_space(mesh, k - 1, 2), ad.dg_space(mesh, k - 1, 1)
+
+
+def _bd_homogeneous(c, mesh, k, ft, V, custom, stress=False):
+    """BoundaryData with homogeneous flux BCs on the facets of type 2 (kernel pointer 0)."""
+    nrhs = ft.shape[0]
+    nq = c.facet_quadrature(c.interpolation_quadrature_degree(k))[0].size
+    bcs = [[c.FluxBC(V, [int(f) for f in np.nonzero(ft[r] == 2)[0]], 0, nq, [], [], [])] for r in range(nrhs)]
+    bfl = [c.Function(V) for _ in range(nrhs)]
+    prime = [[int(f) for f in np.nonzero(ft[r] == 1)[0]] for r in range(nrhs)]
+    return c.BoundaryData(bcs, bfl, V, custom, 2 * (k - 1), prime, stress)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 2, 3])
+@pytest.mark.parametrize("bc", ["dirichlet", "neumann_lt"])
+def test_semiexplt_through_the_module(oracle_mod, k, bc):
+    from dolfinx_eqlb_amd import _cpp as c
+    mesh, ft, G, f = make_case(7, k, bc, nrhs=2)
+    V, Vg, Vf = _spaces(mesh, k)
+    bd = _bd_homogeneous(c, mesh, k, ft, V, True)
+    assert np.array_equal(bd.facet_type, ft)
+    flux = [c.Function(V) for _ in range(2)]
+    c.reconstruct_fluxes_semiexplt(flux, [c.Function(Vg, G[r].copy()) for r in range(2)],
+                                   [c.Function(Vf, f[r].copy()) for r in range(2)], bd, False)
+    ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f)
+    for r in range(2):
+        assert np.abs(flux[r].array - ref[r]).max() <= 1e-11 * np.abs(ref).max()
+    # in place and accumulating, like the reference (se/solve_patch_semiexplt.hpp:1157-1160)
+    x0 = flux[0].array.copy()
+    c.reconstruct_fluxes_semiexplt(flux, [c.Function(Vg, G[r].copy()) for r in range(2)],
+                                   [c.Function(Vf, f[r].copy()) for r in range(2)], bd, False)
+    assert np.allclose(flux[0].array, 2 * x0, rtol=1e-14, atol=0)
+
+
+@pytest.mark.gpu
+def test_korn_and_stress_through_the_module(oracle_mod):
+    from test_oracle_stress import stress_case
+    from dolfinx_eqlb_amd import _cpp as c
+    from dolfinx_eqlb_amd.eqlb import _adapter as ad
+    k = 2
+    mesh, ft, G, f = stress_case(7, k, "neumann_bottom")
+    V, Vg, Vf = _spaces(mesh, k)
+    bd = _bd_homogeneous(c, mesh, k, ft, V, True, stress=True)
+    flux = [c.Function(V) for _ in range(2)]
+    korn = c.Function(ad.dg_space(mesh, 0, 1))
+    c.reconstruct_fluxes_semiexplt_with_kornconst(flux, [c.Function(Vg, G[r].copy()) for r in range(2)],
+                                                  [c.Function(Vf, f[r].copy()) for r in range(2)], bd, True, korn)
+    ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f, stress=True)
+    for r in range(2):
+        assert np.abs(flux[r].array - ref[r]).max() <= 1e-10 * np.abs(ref).max()
+    kref = oracle_mod.se_korn(mesh, ft)
+    assert np.abs(korn.array - kref).max() <= 1e-11 * kref.max()
+    with pytest.raises(RuntimeError, match="reconstruct_stress"):
+        c.reconstruct_fluxes_semiexplt(flux, [c.Function(Vg, G[r].copy()) for r in range(2)],
+                                       [c.Function(Vf, f[r].copy()) for r in range(2)], bd, False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_minimisation_through_the_module(oracle_mod, k):
+    from dolfinx_eqlb_amd import _cpp as c
+    from dolfinx_eqlb_amd.eqlb import _adapter as ad
+    from dolfinx_eqlb_amd.eqlb.conforming import conforming_dofmap
+    mesh, ft, G, f = make_case(7, k, "neumann_lt")
+    V = ad.flux_space(mesh, k, False)
+    Vg, Vf = ad.dg_space(mesh, k - 1, 2), ad.dg_space(mesh, k - 1, 1)
+    cd, nd = conforming_dofmap(mesh, k)
+    assert V.ndofs == nd
+    bd = _bd_homogeneous(c, mesh, k, ft, V, False)
+    flux = [c.Function(V)]
+    form_l = [c.Form([c.Function(Vg, G[0].copy()), c.Function(Vf, f[0].copy())])]
+    c.reconstruct_fluxes_minimisation(c.Form([]), c.Form([]), form_l, flux, bd)
+    ref = oracle_mod.ev_reconstruct(mesh, k, ft, G, f, cd, nd)
+    assert np.abs(flux[0].array - ref[0]).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+    with pytest.raises(RuntimeError, match="discontinuous"):
+        Vs, _, _ = _spaces(mesh, k)
+        c.reconstruct_fluxes_minimisation(c.Form([]), c.Form([]), form_l, flux, _bd_homogeneous(c, mesh, k, ft, Vs, True))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["lu", "cholesky", "cg"])
+def test_local_solvers_through_the_module(solver):
+    from dolfinx_eqlb_amd import _cpp as c
+    from dolfinx_eqlb_amd.elmtlib.quadrature import make_quadrature_triangle
+    from dolfinx_eqlb_amd.eqlb import _adapter as ad
+    from dolfinx_eqlb_amd.lsolver.projection import quadrature_points_physical
+    from oracle import projection as op
+    deg, bs = 2, 2
+    mesh, *_ = make_case(6, 1)
+    qp, qw = make_quadrature_triangle(2 * deg + 3)
+    xq = quadrature_points_physical(mesh, qp)
+    qv = np.stack([np.sin(3 * xq[..., 0]) * np.cos(2 * xq[..., 1]), np.exp(xq[..., 0] - xq[..., 1])], axis=-1)
+    V = ad.dg_space(mesh, deg, bs)
+    sol = [c.Function(V), c.Function(V)]
+    forms = [c.Form.from_point_values(qp, qw, qv), c.Form.from_point_values(qp, qw, 2 * qv)]
+    getattr(c, "local_solver_" + solver)(sol, c.Form([]), forms)
+    ref = op.local_projection(mesh, deg, qp, qw, qv[None], bs=bs)[0]
+    assert np.abs(sol[0].array - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert np.allclose(sol[1].array, 2 * sol[0].array, rtol=1e-14)
+    with pytest.raises(RuntimeError, match="Input sizes"):
+        c.local_solver_lu(sol, c.Form([]), forms[:1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 2, 3])
+@pytest.mark.parametrize("projection", [False, True])
+def test_fluxbc_with_a_compiled_boundary_kernel(oracle_mod, k, projection):
+    """FluxBC with the address of a C function of the ufcx tabulate_tensor signature that evaluates
+    the normal flux g at the facet points of the rule in use - what the reference gets from the
+    JIT-compiled UFL expression (bcs.py:66-118, wrappers.cpp:164-172).  Here the kernel is a ctypes
+    callback that reads a coefficient (cell DOFs of a DG0^2 Function holding a constant field) and a
+    Constant, so the packing of coefficients / constants is exercised too."""
+    from dolfinx_eqlb_amd import _cpp as c
+    from dolfinx_eqlb_amd.eqlb import _adapter as ad
+    from dolfinx_eqlb_amd.mesh import create_unit_square
+    from dolfinx_eqlb_amd.synthetic import boundary_dofs_from_field, facet_types, make_compatible_data
+    mesh = create_unit_square(6, shuffle_seed=5, perturb=0.3)
+    ft = facet_types(mesh, BCS["neumann_lt"])
+    w0, scale = np.array([0.8, -0.6]), 1.5
+
+    def w(x, y):  # prescribed field: scale * w0 (+ a linear part for k >= 2)
+        lin = 0.0 if k == 1 else 1.0
+        return scale * w0[0] + lin * (0.5 * x - 0.3 * y), scale * w0[1] + lin * (0.2 * x + 0.4 * y)
+
+    G, f = make_compatible_data(mesh, k, ft, neumann_flux=w)
+    bv = boundary_dofs_from_field(mesh, k, ft[0], w)
+    V, Vg, Vf = _spaces(mesh, k)
+    qdeg = 2 * k + 2 if projection else c.interpolation_quadrature_degree(k)
+    s, _ = c.facet_quadrature(qdeg)
+    nq = s.size
+    z = np.zeros_like(s)
+    pts = np.stack([np.stack([1 - s, s], 1), np.stack([z, s], 1), np.stack([s, z], 1)])
+    proto = ctypes.CFUNCTYPE(None, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                             ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint8))
+
+    def kernel(values, coef, const, coords, entity, perm):
+        x = np.ctypeslib.as_array(coords, shape=(3, 3))[:, :2]
+        J = np.stack([x[1] - x[0], x[2] - x[0]], axis=1)
+        xq = x[0] + pts @ J.T
+        wc = np.ctypeslib.as_array(coef, shape=(2,)) * const[0]  # coefficient (DG0^2 cell value) x constant
+        lin = 0.0 if k == 1 else 1.0
+        wx = wc[0] + lin * (0.5 * xq[..., 0] - 0.3 * xq[..., 1])
+        wy = wc[1] + lin * (0.2 * xq[..., 0] + 0.4 * xq[..., 1])
+        out = np.ctypeslib.as_array(values, shape=(3, nq))
+        for fl, (a, b) in enumerate(((1, 2), (0, 2), (0, 1))):
+            t = x[b] - x[a]
+            n = np.array([t[1], -t[0]]) / np.hypot(*t)
+            if n @ (x[fl] - x[a]) > 0:
+                n = -n
+            out[fl] = wx[fl] * n[0] + wy[fl] * n[1]
+
+    cb = proto(kernel)
+    ptr = ctypes.cast(cb, ctypes.c_void_p).value
+    coef = c.Function(ad.dg_space(mesh, 0, 2), np.tile(w0, mesh.ncells))
+    const = c.Constant(np.array([scale]))
+    dual = [int(x_) for x_ in np.nonzero(ft[0] == 2)[0]]
+    bc = c.FluxBC(V, dual, ptr, nq, qdeg, [coef], [0], [const]) if projection \
+        else c.FluxBC(V, dual, ptr, nq, [coef], [0], [const])
+    assert bc.quadrature_degree == (qdeg if projection else 0)
+    bfl = [c.Function(V)]
+    prime = [[int(x_) for x_ in np.nonzero(ft[0] == 1)[0]]]
+    bd = c.BoundaryData([[bc]], bfl, V, True, qdeg if projection else 2 * (k - 1), prime, False)
+    assert np.abs(bfl[0].array - bv).max() <= 1e-12 * np.abs(bv).max()  # written in place (BoundaryData.cpp:609)
+    flux = [c.Function(V)]
+    c.reconstruct_fluxes_semiexplt(flux, [c.Function(Vg, G.copy())], [c.Function(Vf, f.copy())], bd, False)
+    ref = oracle_mod.se_reconstruct(mesh, k, ft, G[None], f[None], boundary_values=bv[None])[0]
+    assert np.abs(flux[0].array - ref).max() <= 1e-11 * np.abs(ref).max()
+    # the number of evaluation points has to fit the rule (base/BoundaryData.cpp:437-445)
+    bad = c.FluxBC(V, dual, ptr, nq + 1, [coef], [0], [const])
+    with pytest.raises(RuntimeError, match="Number of evaluation points"):
+        c.BoundaryData([[bad]], [c.Function(V)], V, True, 2 * (k - 1), prime, False)
+
+
+@pytest.mark.gpu
+def test_device_memory_functions(oracle_mod):
+    """Functions over raw device pointers (torch tensors): asynchronous on the stream of set_stream."""
+    import torch
+    from dolfinx_eqlb_amd import _cpp as c
+    k = 2
+    mesh, ft, G, f = make_case(9, k, "neumann_lt")
+    V, Vg, Vf = _spaces(mesh, k)
+    bd = _bd_homogeneous(c, mesh, k, ft, V, True)
+    dev = torch.device("cuda", 0)
+    dG, df = torch.from_numpy(G[0]).to(dev), torch.from_numpy(f[0]).to(dev)
+    dx = torch.zeros(mesh.ncells * k * (k + 2), dtype=torch.float64, device=dev)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    c.reconstruct_fluxes_semiexplt([c.Function.from_device(V, dx.data_ptr())],
+                                   [c.Function.from_device(Vg, dG.data_ptr())],
+                                   [c.Function.from_device(Vf, df.data_ptr())], bd, False)
+    c.synchronize_and_check(bd)
+    ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f)[0]
+    assert np.abs(dx.cpu().numpy() - ref).max() <= 1e-11 * np.abs(ref).max()
+    c.set_stream(0)
+    with pytest.raises(RuntimeError, match="same memory space"):
+        c.reconstruct_fluxes_semiexplt([c.Function(V)], [c.Function.from_device(Vg, dG.data_ptr())],
+                                       [c.Function.from_device(Vf, df.data_ptr())], bd, False)
+
+
+@pytest.mark.gpu
+def test_error_conventions_of_the_module():
+    from dolfinx_eqlb_amd import _cpp as c
+    mesh, ft, G, f = make_case(5, 2)
+    V, Vg, Vf = _spaces(mesh, 2)
+    bd = _bd_homogeneous(c, mesh, 2, ft, V, True)
+    with pytest.raises(RuntimeError, match="Input sizes"):  # se/reconstruction.hpp:358-362
+        c.reconstruct_fluxes_semiexplt([c.Function(V)], [], [c.Function(Vf)], bd, False)
+    with pytest.raises(RuntimeError, match="Specify all rows"):  # :376-381
+        c.reconstruct_fluxes_semiexplt([c.Function(V)], [c.Function(Vg)], [c.Function(Vf)], bd, True)
+    with pytest.raises(RuntimeError, match="Size of input data"):
+        c.BoundaryData([[]], [], V, True, 2, [[]], False)
+    with pytest.raises(RuntimeError):
+        c.Function(V, np.zeros(3))
