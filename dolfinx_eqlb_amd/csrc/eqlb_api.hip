@@ -239,14 +239,24 @@ void rcb_split(TileItem* a, int64_t n, int64_t ntile, int tc, RcbCtx& c)
 
 // Tiled SoA of the plain flux equilibration (EQLB_SCATTER_TILED): cells bisected recursively by
 // their centroids into tiles of TC cells; a tile lists every (masked-in) node of its cells.
-int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin, eqlb::BuildArgs a)
+int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::BuildArgs a, int tc_fixed = 0, int max_bin = eqlb::MAX_BINS)
 {
+  // nodes of bins >= max_bin are left out (like masked-out nodes): another path equilibrates them
+  std::vector<int8_t> node_bin(node_bin_all);
+  h->t_rest = 0;
+  for (auto& b : node_bin)
+    if (b >= max_bin)
+    {
+      b = -1;
+      ++h->t_rest;
+    }
   const eqlb::DeviceMesh& m = h->mesh->m;
   const int32_t nc = m.ncells;
   // Tile size: the default, or - on meshes that fill the chip several times over - the size that
   // makes the tiles fill whole rounds of the 512 workgroup slots (2 per CU): 1M triangles in 2 045
   // tiles of 489 cells run in 4 rounds, 2 084 tiles of 480 cells leave 36 tiles for a fifth
-  int TC = eqlb::tile_cells_of(h->k);
+  int TC = tc_fixed > 0 ? tc_fixed : eqlb::tile_cells_of(h->k);
+  if (tc_fixed <= 0)
   {
     const int64_t slots = 512, tcmax = eqlb::tile_cells_max_of(h->k);
     if (h->k <= 2 && (int64_t)nc >= slots * 256)
@@ -786,9 +796,11 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
   eqlb::launch_build_patches(a, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
-  if (!h->stress && (h->mode == 0 || h->k <= 2))
+  h->t_stress = h->stress && h->k == 2 && !h->stress_flux_bcs && h->mode == 0;
+  if (h->t_stress || (!h->stress && (h->mode == 0 || h->k <= 2)))
   {
-    const int stt = build_tiles(h, node_bin, a);
+    // fused stress launch: its own tile size, patches of up to 8 facets (bins 0, 1)
+    const int stt = h->t_stress ? build_tiles(h, node_bin, a, eqlb::stress_tile_cells(), 2) : build_tiles(h, node_bin, a);
     if (stt)
       return stt;
     if (h->mode == 1)
@@ -979,8 +991,11 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
   // EQLB_SCATTER_AUTO: the tiled launch where it applies and is the fastest (k <= 2, plain flux
   // equilibration, shuffle solver), else slots + reduction
   int scatter_eff = h->scatter;
+  // stress of RT_2 without flux BCs on the stress rows: rows 0, 1 and their weak symmetry in one tiled launch
+  const bool stress_fused = h->stress && h->t_stress && h->ntiles > 0 && h->solver == EQLB_SOLVER_SHUFFLE
+                            && (scatter_eff == EQLB_SCATTER_AUTO || scatter_eff == EQLB_SCATTER_TILED);
   if (scatter_eff == EQLB_SCATTER_AUTO)
-    scatter_eff = (!h->stress && h->k <= 2 && h->solver == EQLB_SOLVER_SHUFFLE && h->ntiles > 0)
+    scatter_eff = (stress_fused || (!h->stress && h->k <= 2 && h->solver == EQLB_SOLVER_SHUFFLE && h->ntiles > 0))
                       ? EQLB_SCATTER_TILED
                       : EQLB_SCATTER_SLOTS;
   h->scatter_last = scatter_eff;
@@ -1017,13 +1032,6 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
   else if (memspace != EQLB_MEM_DEVICE)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_equilibrate: unknown memory space");
 
-  if (scatter_eff == EQLB_SCATTER_SLOTS && !h->slots)
-  {
-    if (upload<double>(&h->slots, nullptr, n_slot * 3))
-      return EQLB_ERR_DEVICE;
-    // slots of (cell, vertex) pairs whose node is not equilibrated (node_mask) stay zero
-    HIP_TRY(hipMemset(h->slots, 0, n_slot * 3 * sizeof(double)));
-  }
   hipEvent_t* evs = nullptr;
   if (h->timing)
   {
@@ -1059,127 +1067,105 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
   a.nrhs = h->nrhs;
   // data of right-hand side r: the kernels address block rhs_in of flux_dg / rhs_dg and block rhs_out
   // of out; the caller's arrays arrive block by block, the slot buffer is one array
-  auto select_rhs = [&](int r) {
-    a.rhs = r;
-    a.flux_dg = d_g[r];
-    a.rhs_dg = d_f[r];
-    a.rhs_in = 0;
-    if (scatter_eff == EQLB_SCATTER_SLOTS)
+  auto select_rhs = [&](eqlb::SeArgs& aa, int r, bool to_slots) {
+    aa.rhs = r;
+    aa.flux_dg = d_g[r];
+    aa.rhs_dg = d_f[r];
+    aa.rhs_in = 0;
+    if (to_slots)
     {
-      a.out = h->slots;
-      a.rhs_out = r;
+      aa.out = h->slots;
+      aa.rhs_out = r;
     }
     else
     {
-      a.out = d_x[r];
-      a.rhs_out = 0;
+      aa.out = d_x[r];
+      aa.rhs_out = 0;
     }
   };
 
-  const bool tiled = scatter_eff == EQLB_SCATTER_TILED;
-  if (tiled)
-  {
-    if (h->stress || h->solver != EQLB_SOLVER_SHUFFLE || h->ntiles == 0)
-      return fail(EQLB_ERR_UNSUPPORTED,
-                  "the tiled scatter is available for k <= 2 flux equilibration with the shuffle solver");
-    if (h->tile_first > h->ntiles)
-      return fail(EQLB_ERR_INVALID_ARGUMENT, "tile_first %d beyond the %d tiles", h->tile_first, h->ntiles);
-    const int32_t tcount = (h->tile_count < 0) ? h->ntiles - h->tile_first
-                                               : std::min(h->tile_count, h->ntiles - h->tile_first);
-    eqlb::TileArgs ta{h->t_tiles, h->t_tile_cells, tcount, h->tile_tc,
-                      ev_conf ? h->t_facet_owner : nullptr, h->ev_cell_dofs, h->ev_ndofs, m.nfacets,
-                      h->tile_first, h->accumulate};
-    a.slot_cell = h->t_slot_cell;
-    a.slot_info = h->t_slot_info;
-    a.pn = h->t_pn;
-    a.pflag = h->t_pflag;
-    a.npatch_total = h->t_npatch;
-    for (int r = 0; r < h->nrhs; ++r)
+  // ---- slot path: (cell, vertex) rows into the slot buffer, weak symmetry on the slot rows, reduction.
+  // first_bin > 0: only the patches of the bins >= first_bin (the rest of a fused stress launch);
+  // their sums are ADDED to what the tiled launch wrote ----
+  auto run_slot_path = [&](int first_bin, int accumulate) -> int {
+    if (!h->slots)
     {
-      select_rhs(r);
-      if (evs && r == 0)
-        HIP_TRY(hipEventRecord(evs[0], stream));
-      const int st = eqlb::launch_se_patch_tiled(h->k, h->deg, h->mode, a, ta, stream);
-      if (st)
-        return fail(st, "tiled patch kernel launch failed (k=%d)", h->k);
+      if (upload<double>(&h->slots, nullptr, n_slot * 3))
+        return EQLB_ERR_DEVICE;
+      // slots of (cell, vertex) pairs whose node is not equilibrated here (node_mask, other path) stay zero
+      HIP_TRY(hipMemset(h->slots, 0, n_slot * 3 * sizeof(double)));
     }
-    if (evs)
-      HIP_TRY(hipEventRecord(evs[1], stream));
-  }
-  else if (h->mode == 1 || (h->fused && h->solver == EQLB_SOLVER_SHUFFLE))
-  {
-    // all bins in one launch; timing slot 0 holds the fused kernel
-    eqlb::FusedBins fb{};
-    int64_t nb = 0;
-    for (int b = 0; b < eqlb::MAX_BINS; ++b)
+    eqlb::SeArgs as = a;
+    if (h->mode == 1 || (h->fused && h->solver == EQLB_SOLVER_SHUFFLE))
     {
-      fb.block_start[b] = nb;
-      fb.npatch[b] = h->bins[b].npatch;
-      fb.slot_offset[b] = h->bins[b].slot_offset;
-      fb.patch_offset[b] = h->bins[b].patch_offset;
-      nb += (h->bins[b].npatch * h->bins[b].P + 255) / 256;
+      // all bins in one launch; timing slot 0 holds the fused kernel
+      eqlb::FusedBins fb{};
+      int64_t nb = 0;
+      for (int b = 0; b < eqlb::MAX_BINS; ++b)
+      {
+        fb.block_start[b] = nb;
+        fb.npatch[b] = (b >= first_bin) ? h->bins[b].npatch : 0;
+        fb.slot_offset[b] = h->bins[b].slot_offset;
+        fb.patch_offset[b] = h->bins[b].patch_offset;
+        nb += (fb.npatch[b] * h->bins[b].P + 255) / 256;
+      }
+      fb.block_start[eqlb::MAX_BINS] = nb;
+      for (int r = 0; r < h->nrhs; ++r)
+      {
+        select_rhs(as, r, true);
+        if (evs && r == 0 && first_bin == 0)
+          HIP_TRY(hipEventRecord(evs[0], stream));
+        const int st = (h->mode == 1) ? eqlb::launch_ev_patch_fused(h->k, as, fb, stream)
+                                      : eqlb::launch_se_patch_fused(h->k, h->deg, EQLB_SCATTER_SLOTS, as, fb, stream);
+        if (st)
+          return fail(st, "fused patch kernel launch failed (k=%d)", h->k);
+      }
+      if (evs && first_bin == 0)
+        HIP_TRY(hipEventRecord(evs[1], stream));
     }
-    fb.block_start[eqlb::MAX_BINS] = nb;
-    for (int r = 0; r < h->nrhs; ++r)
+    else
+      for (int b = first_bin; b < eqlb::MAX_BINS; ++b)
+      {
+        if (h->bins[b].npatch == 0)
+          continue;
+        as.npatch = h->bins[b].npatch;
+        as.slot_offset = h->bins[b].slot_offset;
+        as.patch_offset = h->bins[b].patch_offset;
+        if (evs && first_bin == 0)
+          HIP_TRY(hipEventRecord(evs[2 * b], stream));
+        for (int r = 0; r < h->nrhs; ++r)
+        {
+          select_rhs(as, r, true);
+          const int st = eqlb::launch_se_patch(h->k, h->deg, h->bins[b].P, h->solver, EQLB_SCATTER_SLOTS, as, stream);
+          if (st)
+            return fail(st, "patch kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
+        }
+        if (evs && first_bin == 0)
+          HIP_TRY(hipEventRecord(evs[2 * b + 1], stream));
+      }
+    if (h->stress)
     {
-      select_rhs(r);
-      if (evs && r == 0)
-        HIP_TRY(hipEventRecord(evs[0], stream));
-      const int st = (h->mode == 1) ? eqlb::launch_ev_patch_fused(h->k, a, fb, stream)
-                                    : eqlb::launch_se_patch_fused(h->k, h->deg, scatter_eff, a, fb, stream);
-      if (st)
-        return fail(st, "fused patch kernel launch failed (k=%d)", h->k);
+      // weak symmetry of rows 0, 1 on the patch-local stresses held in the slots
+      // (se/reconstruction.hpp:237-270; the grouped boundary patches of :170-234 are flagged by the
+      // patch builder: PFLAG_WS_SKIP / PFLAG_WS_GROUP)
+      if (evs && first_bin == 0)
+        HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS + 2], stream));
+      select_rhs(as, 0, true); // the kernel works on the slot rows of RHS 0 and 1
+      for (int b = first_bin; b < eqlb::MAX_BINS; ++b)
+      {
+        if (h->bins[b].npatch == 0)
+          continue;
+        as.npatch = h->bins[b].npatch;
+        as.slot_offset = h->bins[b].slot_offset;
+        as.patch_offset = h->bins[b].patch_offset;
+        const int st = eqlb::launch_se_weaksym(h->k, h->bins[b].P, !h->stress_flux_bcs, as, stream);
+        if (st)
+          return fail(st, "weak-symmetry kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
+      }
+      if (evs && first_bin == 0)
+        HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS + 3], stream));
     }
-    if (evs)
-      HIP_TRY(hipEventRecord(evs[1], stream));
-  }
-  else
-  for (int b = 0; b < eqlb::MAX_BINS; ++b)
-  {
-    if (h->bins[b].npatch == 0)
-      continue;
-    a.npatch = h->bins[b].npatch;
-    a.slot_offset = h->bins[b].slot_offset;
-    a.patch_offset = h->bins[b].patch_offset;
-    if (evs)
-      HIP_TRY(hipEventRecord(evs[2 * b], stream));
-    for (int r = 0; r < h->nrhs; ++r)
-    {
-      select_rhs(r);
-      const int st = eqlb::launch_se_patch(h->k, h->deg, h->bins[b].P, h->solver, scatter_eff, a, stream);
-      if (st)
-        return fail(st, "patch kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
-    }
-    if (evs)
-      HIP_TRY(hipEventRecord(evs[2 * b + 1], stream));
-  }
-  if (h->stress)
-  {
-    // weak symmetry of rows 0, 1 on the patch-local stresses held in the slots
-    // (se/reconstruction.hpp:237-270; the grouped boundary patches of :170-234 are flagged by the
-    // patch builder: PFLAG_WS_SKIP / PFLAG_WS_GROUP)
-    if (scatter_eff != EQLB_SCATTER_SLOTS)
-      return fail(EQLB_ERR_UNSUPPORTED, "stress equilibration needs the slot scatter");
-    if (evs)
-      HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS + 2], stream));
-    select_rhs(0); // the kernel works on the slot rows of RHS 0 and 1
-    for (int b = 0; b < eqlb::MAX_BINS; ++b)
-    {
-      if (h->bins[b].npatch == 0)
-        continue;
-      a.npatch = h->bins[b].npatch;
-      a.slot_offset = h->bins[b].slot_offset;
-      a.patch_offset = h->bins[b].patch_offset;
-      const int st = eqlb::launch_se_weaksym(h->k, h->bins[b].P, !h->stress_flux_bcs, a, stream);
-      if (st)
-        return fail(st, "weak-symmetry kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
-    }
-    if (evs)
-      HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS + 3], stream));
-  }
-  if (scatter_eff == EQLB_SCATTER_SLOTS)
-  {
-    if (evs)
+    if (evs && first_bin == 0)
       HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS], stream));
     // blocks that lie behind one another (one array, the usual case) are reduced by one launch
     bool contiguous = true;
@@ -1190,12 +1176,124 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
     {
       const double* sl = h->slots + (size_t)l * s_slot * 3;
       if (ev_conf)
-        eqlb::launch_ev_reduce(m, h->k, per, h->ev_cell_dofs, h->ev_ndofs, sl, d_x[l], h->accumulate, stream);
-      else if (eqlb::launch_reduce_slots(h->nrt, m.ncells, per, sl, d_x[l], h->accumulate, stream))
+        eqlb::launch_ev_reduce(m, h->k, per, h->ev_cell_dofs, h->ev_ndofs, sl, d_x[l], accumulate, stream);
+      else if (eqlb::launch_reduce_slots(h->nrt, m.ncells, per, sl, d_x[l], accumulate, stream))
         return fail(EQLB_ERR_UNSUPPORTED, "slot reduction for %d DOFs per cell is not in this build", h->nrt);
     }
-    if (evs)
+    if (evs && first_bin == 0)
       HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS + 1], stream));
+    return EQLB_OK;
+  };
+
+  if (scatter_eff == EQLB_SCATTER_TILED)
+  {
+    if ((h->stress && !stress_fused) || h->solver != EQLB_SOLVER_SHUFFLE || h->ntiles == 0)
+      return fail(EQLB_ERR_UNSUPPORTED,
+                  "the tiled scatter is available for k <= 2 with the shuffle solver (stress: RT_2 without "
+                  "flux boundary conditions on the stress rows)");
+    if (h->tile_first > h->ntiles)
+      return fail(EQLB_ERR_INVALID_ARGUMENT, "tile_first %d beyond the %d tiles", h->tile_first, h->ntiles);
+    const int32_t tcount = (h->tile_count < 0) ? h->ntiles - h->tile_first
+                                               : std::min(h->tile_count, h->ntiles - h->tile_first);
+    eqlb::TileArgs ta{h->t_tiles, h->t_tile_cells, tcount, h->tile_tc,
+                      ev_conf ? h->t_facet_owner : nullptr, h->ev_cell_dofs, h->ev_ndofs, m.nfacets,
+                      h->tile_first, h->accumulate};
+    eqlb::SeArgs at = a;
+    at.slot_cell = h->t_slot_cell;
+    at.slot_info = h->t_slot_info;
+    at.pn = h->t_pn;
+    at.pflag = h->t_pflag;
+    at.npatch_total = h->t_npatch;
+    if (evs)
+      HIP_TRY(hipEventRecord(evs[0], stream));
+    int r0 = 0;
+    if (stress_fused)
+    {
+      // rows 0, 1 of the stress and their weak symmetry in one launch
+      select_rhs(at, 0, false);
+      const int st = eqlb::launch_se_stress_tiled(at, ta, d_g.data(), d_f.data(), d_x.data(), stream);
+      if (st)
+        return fail(st, "fused stress kernel launch failed");
+      r0 = 2;
+    }
+    for (int r = r0; r < h->nrhs; ++r)
+    {
+      select_rhs(at, r, false);
+      const int st = eqlb::launch_se_patch_tiled(h->k, h->deg, h->mode, at, ta, stream);
+      if (st)
+        return fail(st, "tiled patch kernel launch failed (k=%d)", h->k);
+    }
+    if (evs)
+      HIP_TRY(hipEventRecord(evs[1], stream));
+    // patches of more than 8 facets of a fused stress launch: generic kernels, sums added (with the last
+    // range of tiles of a two-phase sweep)
+    if (stress_fused && h->t_rest > 0 && h->tile_first + tcount == h->ntiles)
+    {
+      hipEvent_t* keep = evs;
+      evs = nullptr;
+      const int st = run_slot_path(2, 1);
+      evs = keep;
+      if (st)
+        return st;
+    }
+  }
+  else if (scatter_eff == EQLB_SCATTER_SLOTS)
+  {
+    const int st = run_slot_path(0, h->accumulate);
+    if (st)
+      return st;
+  }
+  else
+  {
+    // fp64 global atomics straight into flux_hdiv
+    if (h->stress)
+      return fail(EQLB_ERR_UNSUPPORTED, "stress equilibration needs the slot or the tiled scatter");
+    eqlb::SeArgs aa = a;
+    if (h->fused && h->solver == EQLB_SOLVER_SHUFFLE)
+    {
+      eqlb::FusedBins fb{};
+      int64_t nb = 0;
+      for (int b = 0; b < eqlb::MAX_BINS; ++b)
+      {
+        fb.block_start[b] = nb;
+        fb.npatch[b] = h->bins[b].npatch;
+        fb.slot_offset[b] = h->bins[b].slot_offset;
+        fb.patch_offset[b] = h->bins[b].patch_offset;
+        nb += (h->bins[b].npatch * h->bins[b].P + 255) / 256;
+      }
+      fb.block_start[eqlb::MAX_BINS] = nb;
+      for (int r = 0; r < h->nrhs; ++r)
+      {
+        select_rhs(aa, r, false);
+        if (evs && r == 0)
+          HIP_TRY(hipEventRecord(evs[0], stream));
+        const int st = eqlb::launch_se_patch_fused(h->k, h->deg, scatter_eff, aa, fb, stream);
+        if (st)
+          return fail(st, "fused patch kernel launch failed (k=%d)", h->k);
+      }
+      if (evs)
+        HIP_TRY(hipEventRecord(evs[1], stream));
+    }
+    else
+      for (int b = 0; b < eqlb::MAX_BINS; ++b)
+      {
+        if (h->bins[b].npatch == 0)
+          continue;
+        aa.npatch = h->bins[b].npatch;
+        aa.slot_offset = h->bins[b].slot_offset;
+        aa.patch_offset = h->bins[b].patch_offset;
+        if (evs)
+          HIP_TRY(hipEventRecord(evs[2 * b], stream));
+        for (int r = 0; r < h->nrhs; ++r)
+        {
+          select_rhs(aa, r, false);
+          const int st = eqlb::launch_se_patch(h->k, h->deg, h->bins[b].P, h->solver, scatter_eff, aa, stream);
+          if (st)
+            return fail(st, "patch kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
+        }
+        if (evs)
+          HIP_TRY(hipEventRecord(evs[2 * b + 1], stream));
+      }
   }
   if (evs)
     ++h->ev_calls;

@@ -163,6 +163,10 @@ void launch_tile_facet_owner(const DeviceMesh& m, int64_t n, const int32_t* tile
 int tile_cells_of(int k);
 int tile_cells_max_of(int k);
 int launch_se_weaksym(int k, int P, bool no_flux_bcs, const SeArgs& a, hipStream_t stream);
+// fused stress launch (RT_2, no stress flux BCs, patches of up to 8 facets): rows 0, 1 + weak symmetry
+int launch_se_stress_tiled(const SeArgs& a, const TileArgs& t, const double* const* g, const double* const* f,
+                           double* const* x, hipStream_t stream);
+int stress_tile_cells();
 int launch_ev_patch_fused(int k, const SeArgs& a, const FusedBins& fb, hipStream_t stream);
 // conforming <-> broken layout of the EV equilibrator (eqlb_ev.hip); cell_dofs may be nullptr
 // (default numbering: facet*k + j, then nfacets*k + cell*(k^2-k) + i)
@@ -233,6 +237,8 @@ struct eqlb_se
   uint8_t* pflag = nullptr;
   // tiled SoA (plain SE, EQLB_SCATTER_TILED)
   int32_t ntiles = 0, tile_tc = 0;
+  bool t_stress = false;            // the tiles serve the fused stress launch (bins P <= 8 only)
+  int64_t t_rest = 0;               // patches left to the generic kernels (bins P >= 16) when t_stress
   int64_t t_nslots = 0, t_npatch = 0;
   eqlb::TileDesc* t_tiles = nullptr;
   int32_t *t_tile_cells = nullptr, *t_slot_cell = nullptr, *t_facet_owner = nullptr;

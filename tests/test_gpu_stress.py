@@ -121,3 +121,77 @@ def test_stress_pivot_free_solve_on_stretched_perturbed_mesh(oracle_mod, aspect)
     tol = 1e-10 if aspect <= 20.0 else 1e-8
     assert np.abs(x - ref).max() <= tol * np.abs(ref).max()
     assert np.abs(asym_moments(mesh, k, x)[1]).max() < 1e-9 * max(1.0, np.abs(ref).max())
+
+
+def _stress_both_paths(mesh, k, ft, G, f, node_mask=None):
+    """(fused tiled launch, slot path) results of the same problem."""
+    from dolfinx_eqlb_amd import cpp
+    dm = cpp.DeviceMesh(mesh)
+    out = []
+    for scatter in (-1, 0):
+        eq = cpp.SemiExplicitEquilibrator(dm, k, G.shape[0], reconstruct_stress=True)
+        eq.set_option("scatter", scatter)
+        eq.set_boundary(ft, node_mask=node_mask)
+        out.append(eq.equilibrate_host(G, f))
+    return out
+
+
+@pytest.mark.parametrize("n,shuffle", [(7, 5), (24, None), (24, 11)])
+def test_fused_stress_launch_equals_slot_path_and_oracle(oracle_mod, n, shuffle):
+    """RT_2 without flux BCs on the stress rows: rows 0, 1 and the weak-symmetry step in ONE tiled launch
+    (k_se_stress_tiled, the default) against the slot path (row sweeps, k_se_weaksym_lean, reduction) and
+    the oracle; several tiles with rims at n = 24."""
+    from dolfinx_eqlb_amd.mesh import create_unit_square
+    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_stress_data
+    k = 2
+    mesh = create_unit_square(n, shuffle_seed=shuffle, perturb=0.25 if shuffle else 0.0)
+    ft = np.repeat(facet_types(mesh, None), 2, axis=0)
+    G, f = make_compatible_stress_data(mesh, k, ft)
+    fused, slots = _stress_both_paths(mesh, k, ft, G, f)
+    ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f, stress=True)
+    assert np.abs(fused - ref).max() <= 1e-10 * np.abs(ref).max()
+    assert np.abs(fused - slots).max() <= 1e-11 * np.abs(ref).max()
+    assert np.abs(asym_moments(mesh, k, fused)[1]).max() < 1e-11
+    # a third right-hand side rides along as a plain flux (rows >= gdim, se/reconstruction.hpp:237-270)
+    from dolfinx_eqlb_amd.synthetic import make_compatible_data
+    G3, f3 = make_compatible_data(mesh, k, ft[:1], seed=99)
+    ft3 = np.concatenate([ft, ft[:1]])
+    fused3, slots3 = _stress_both_paths(mesh, k, ft3, np.concatenate([G, G3[None]]), np.concatenate([f, f3[None]]))
+    assert np.array_equal(fused3[:2], fused)
+    plain = oracle_mod.se_reconstruct(mesh, k, ft[:1], G3[None], f3[None])
+    assert np.abs(fused3[2] - plain[0]).max() <= 1e-11 * np.abs(plain).max()
+    assert np.abs(slots3[2] - plain[0]).max() <= 1e-11 * np.abs(plain).max()
+
+
+@pytest.mark.parametrize("ns", [5, 7, 12, 24])
+def test_fused_stress_launch_with_irregular_valence(oracle_mod, ns):
+    """Interior patches of 5 ... 7 cells run the generic instance of the fused body (fewer cells than lanes);
+    the centre patch of valence 12 / 24 has more than 8 facets and goes through the generic kernels, its
+    rows are added to what the tiled launch wrote."""
+    from dolfinx_eqlb_amd.mesh import create_disk
+    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_stress_data
+    k = 2
+    mesh = create_disk(ns, 3, shuffle_seed=9)
+    ft = np.repeat(facet_types(mesh, None), 2, axis=0)
+    G, f = make_compatible_stress_data(mesh, k, ft)
+    fused, slots = _stress_both_paths(mesh, k, ft, G, f)
+    ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f, stress=True)
+    assert np.abs(fused - ref).max() <= 1e-10 * np.abs(ref).max()
+    assert np.abs(slots - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
+def test_fused_stress_launch_node_mask_and_accumulation(oracle_mod):
+    from dolfinx_eqlb_amd import cpp
+    mesh, ft, G, f = stress_case(16, 2, "dirichlet")
+    mask = (mesh.x[:, 0] < 0.45).astype(np.uint8)
+    a, _ = _stress_both_paths(mesh, 2, ft, G, f, node_mask=mask)
+    b, _ = _stress_both_paths(mesh, 2, ft, G, f, node_mask=1 - mask)
+    full, _ = _stress_both_paths(mesh, 2, ft, G, f)
+    assert np.abs(a + b - full).max() <= 1e-12 * np.abs(full).max()
+    eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(mesh), 2, 2, reconstruct_stress=True)
+    eq.set_boundary(ft)
+    x1 = eq.equilibrate_host(G, f)
+    x2 = eq.equilibrate_host(G, f, x1.copy())
+    assert np.array_equal(x1, full) and np.allclose(x2, 2 * x1, rtol=1e-14, atol=0)
+    eq.set_option("accumulate", 0)
+    assert np.array_equal(eq.equilibrate_host(G, f, np.full_like(x1, 3.0)), x1)
