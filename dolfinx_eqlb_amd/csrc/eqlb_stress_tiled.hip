@@ -162,7 +162,12 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
   const double* sV = lds + Z::NTAB; // [3][NRT][2]
   const double* sVQ = sV + Z::NVT;  // [NCOMBO][2][NH][3]
 
-  const int lane = threadIdx.x & 63;
+  // opaque lane index: keeps the compiler from hoisting the lane predicates (sub == 1, sub < n, ...) of all
+  // four instances of this body out of the wave-block loops of the kernel, where they would occupy
+  // registers across all bins
+  int lane_ = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane_));
+  const int lane = lane_;
   const int sub = lane % P, gbase = lane - sub;
   const int64_t tl = lane_index;
   const int64_t patch_local = tl / P;
