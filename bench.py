@@ -168,7 +168,7 @@ def main():
         if k == 4 and args.solver is None:
             args.solver = 0  # RT_4 runs on the dense LDS Cholesky path (library default for k = 4)
         if args.scatter is None:  # the library default (AUTO): tiled launches for k <= 2, also for the stress
-            args.scatter = 2 if (k <= 2 and args.solver in (None, 1)) else 0
+            args.scatter = 2 if (k <= 3 and args.solver in (None, 1) and not (args.stress and k != 2)) else 0
         eq.set_option("scatter", args.scatter)
         fused = (bool(args.fused) and args.solver in (None, 1)) or args.scatter == 2
         eq.set_option("fused", int(fused))
@@ -246,7 +246,7 @@ def main():
     # on one GPU) the kernel's average duration is taken from two HIP events that bracket the whole
     # timed region on the launch stream (torch's current stream is the stream handed to the
     # library); per-launch event pairs would put ~5 us of barrier packets between the launches.
-    single_kernel = world == 1 and fused and (args.ev and k <= 2 or (not args.ev and args.scatter == 2))
+    single_kernel = world == 1 and fused and (args.ev and k <= 3 or (not args.ev and args.scatter == 2))
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     eq.set_option("timing", 0)  # no per-launch events inside the timed region
     torch.cuda.synchronize()
@@ -275,8 +275,8 @@ def main():
     # event pairs around each kernel group on the launch stream (they would put barrier packets between
     # the launches of the timed region itself).
     bytes_sweep = float(compulsory_bytes_per_cell(k, nrhs, args.ev) * part.ncells_owned)
-    if args.ev:  # library default: tiled launch for k <= 2
-        patch_kernel = f"k_se_patch_tiled<K={k},EV>" if k <= 2 else f"k_ev_patch_fused<K={k}>"
+    if args.ev:  # library default: tiled launch for k <= 3
+        patch_kernel = f"k_se_patch_tiled<K={k},EV>" if k <= 3 else f"k_ev_patch_fused<K={k}>"
     elif args.scatter == 2 and args.stress:
         patch_kernel = "k_se_stress_tiled"
     elif args.scatter == 2:
@@ -361,7 +361,7 @@ def main():
             "partition": ("node-ownership strips, halo exchange behind the interior tiles" if two_phase
                           else "node-ownership strips") if world > 1 else "none",
             "solver": eq_solver_name(None if args.ev else args.solver),
-            "scatter": ("tiled" if k <= 2 else "slots") if args.ev else eq_scatter_name(args.scatter),
+            "scatter": ("tiled" if k <= 3 else "slots") if args.ev else eq_scatter_name(args.scatter),
             "accumulate": bool(args.accumulate),
         },
         "roofline": {

@@ -258,8 +258,12 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
   int TC = tc_fixed > 0 ? tc_fixed : eqlb::tile_cells_of(h->k);
   if (tc_fixed <= 0)
   {
-    const int64_t slots = 512, tcmax = eqlb::tile_cells_max_of(h->k);
-    if (h->k <= 2 && (int64_t)nc >= slots * 256)
+    // resident workgroup slots of the chip: two per CU for k <= 2, one for k = 3
+    const bool ev3 = h->mode == 1 && h->k >= 3; // EV mode of RT_3 stages 7 KB more tensors: smaller tiles
+    const int64_t slots = (h->k <= 2) ? 512 : 256, tcmax = ev3 ? eqlb::tile_cells_ev_of(h->k) : eqlb::tile_cells_max_of(h->k);
+    if (ev3)
+      TC = eqlb::tile_cells_ev_of(h->k);
+    if ((int64_t)nc >= slots * 256)
     {
       const int64_t rounds = ((int64_t)nc + slots * tcmax - 1) / (slots * tcmax);
       TC = (int)(((int64_t)nc + rounds * slots - 1) / (rounds * slots));
@@ -797,7 +801,7 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   h->t_stress = h->stress && h->k == 2 && !h->stress_flux_bcs && h->mode == 0;
-  if (h->t_stress || (!h->stress && (h->mode == 0 || h->k <= 2)))
+  if (h->t_stress || (!h->stress && h->k <= 3))
   {
     // fused stress launch: its own tile size, patches of up to 8 facets (bins 0, 1)
     const int stt = h->t_stress ? build_tiles(h, node_bin, a, eqlb::stress_tile_cells(), 2) : build_tiles(h, node_bin, a);
@@ -988,14 +992,14 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const size_t s_g = (size_t)m.ncells * h->nd * 2, s_f = (size_t)m.ncells * h->nd; // block sizes
   const size_t n_g = (size_t)h->nrhs * s_g, n_f = (size_t)h->nrhs * s_f;
-  // EQLB_SCATTER_AUTO: the tiled launch where it applies and is the fastest (k <= 2, plain flux
+  // EQLB_SCATTER_AUTO: the tiled launch where it applies and is the fastest (k <= 3, plain flux
   // equilibration, shuffle solver), else slots + reduction
   int scatter_eff = h->scatter;
   // stress of RT_2 without flux BCs on the stress rows: rows 0, 1 and their weak symmetry in one tiled launch
   const bool stress_fused = h->stress && h->t_stress && h->ntiles > 0 && h->solver == EQLB_SOLVER_SHUFFLE
                             && (scatter_eff == EQLB_SCATTER_AUTO || scatter_eff == EQLB_SCATTER_TILED);
   if (scatter_eff == EQLB_SCATTER_AUTO)
-    scatter_eff = (stress_fused || (!h->stress && h->k <= 2 && h->solver == EQLB_SOLVER_SHUFFLE && h->ntiles > 0))
+    scatter_eff = (stress_fused || (!h->stress && h->k <= 3 && h->solver == EQLB_SOLVER_SHUFFLE && h->ntiles > 0))
                       ? EQLB_SCATTER_TILED
                       : EQLB_SCATTER_SLOTS;
   h->scatter_last = scatter_eff;
@@ -1189,7 +1193,7 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
   {
     if ((h->stress && !stress_fused) || h->solver != EQLB_SOLVER_SHUFFLE || h->ntiles == 0)
       return fail(EQLB_ERR_UNSUPPORTED,
-                  "the tiled scatter is available for k <= 2 with the shuffle solver (stress: RT_2 without "
+                  "the tiled scatter is available for k <= 3 with the shuffle solver (stress: RT_2 without "
                   "flux boundary conditions on the stress rows)");
     if (h->tile_first > h->ntiles)
       return fail(EQLB_ERR_INVALID_ARGUMENT, "tile_first %d beyond the %d tiles", h->tile_first, h->ntiles);

@@ -161,6 +161,7 @@ int launch_se_patch_tiled(int k, int deg, int mode, const SeArgs& a, const TileA
 void launch_tile_facet_owner(const DeviceMesh& m, int64_t n, const int32_t* tile_cells, int32_t* code,
                              hipStream_t stream);
 int tile_cells_of(int k);
+int tile_cells_ev_of(int k);
 int tile_cells_max_of(int k);
 int launch_se_weaksym(int k, int P, bool no_flux_bcs, const SeArgs& a, hipStream_t stream);
 // fused stress launch (RT_2, no stress flux BCs, patches of up to 8 facets): rows 0, 1 + weak symmetry

@@ -1597,20 +1597,25 @@ int launch_ev_patch_fused(int k, const SeArgs& a, const FusedBins& fb, hipStream
 #define EQLB_FLUSH_NT 0 // nontemporal loads/stores of flux_hdiv in the tile flush
 #endif
 #ifndef EQLB_TILE_THREADS_K3
-#define EQLB_TILE_THREADS_K3 256 // the k = 3 body runs at 2 waves/SIMD: two 4-wave workgroups per CU
+#define EQLB_TILE_THREADS_K3 512 // the k = 3 body runs at 2 waves/SIMD: ONE 8-wave workgroup per CU with the whole LDS
 #endif
-// k <= 2: 8 waves own EQLB_TILE_CELLS cells (two workgroups per CU); k = 3: 4 waves, EQLB_TILE_CELLS_K3 cells
+// k <= 2: 8 waves own EQLB_TILE_CELLS cells (two workgroups per CU); k = 3: 8 waves, EQLB_TILE_CELLS_K3 cells (one per CU)
 constexpr int tile_threads_c(int k) { return (k >= 3) ? EQLB_TILE_THREADS_K3 : EQLB_TILE_THREADS; }
 #ifndef EQLB_TILE_CELLS
 #define EQLB_TILE_CELLS 480 // 480 cells x 18 packed values + tables: two workgroups per CU (SE and EV)
 #endif
 #ifndef EQLB_TILE_CELLS_K3
-#define EQLB_TILE_CELLS_K3 160 // 160 cells x 36 packed values + 32 KB of tables: two workgroups per CU
+#define EQLB_TILE_CELLS_K3 440 // 440 cells x 36 packed values + 32 KB of tables = 158 KB: one workgroup per CU
+                               // (measured at 1M triangles: 256 threads / 160 cells 0.384 ms, 512 / 320 0.366, 512 / 440 0.339)
 #endif
 constexpr int tile_cells_c(int k) { return (k >= 3) ? EQLB_TILE_CELLS_K3 : EQLB_TILE_CELLS; }
+#ifndef EQLB_TILE_CELLS_K3_EV
+#define EQLB_TILE_CELLS_K3_EV 415 // EV mode stages 7 KB more tensors (HG, WG)
+#endif
 // largest tile the LDS budget of two workgroups per CU allows (k <= 2: 490 x 144 B + tensors <= 80 KB)
 constexpr int tile_cells_max_c(int k) { return (k >= 3) ? EQLB_TILE_CELLS_K3 : (EQLB_TILE_CELLS > 490 ? EQLB_TILE_CELLS : 490); }
 int tile_cells_of(int k) { return tile_cells_c(k); }
+int tile_cells_ev_of(int k) { return (k >= 3) ? EQLB_TILE_CELLS_K3_EV : tile_cells_c(k); }
 int tile_cells_max_of(int k) { return tile_cells_max_c(k); }
 
 // facet-owner table of the EV flush: for the owned cell cl of a tile and its local facet lf the
@@ -1906,6 +1911,8 @@ int launch_se_patch_tiled(int k, int deg, int mode, const SeArgs& a, const TileA
       return launch_tiled_kd<1, 0, 1>(a, t, stream);
     if (k == 2)
       return launch_tiled_kd<2, 1, 1>(a, t, stream);
+    if (k == 3)
+      return launch_tiled_kd<3, 2, 1>(a, t, stream);
     return EQLB_ERR_UNSUPPORTED;
   }
   if (k == 1 && deg == 0)

@@ -47,8 +47,8 @@ extern "C" {
 #define EQLB_SOLVER_SHUFFLE 1      /* block-tridiagonal elimination in registers, wave shuffles */
 #define EQLB_SCATTER_SLOTS 0       /* per-(cell, vertex) slots + deterministic reduction */
 #define EQLB_SCATTER_ATOMIC 1      /* fp64 global atomic add into the RT coefficient vector */
-#define EQLB_SCATTER_AUTO (-1)     /* default: TILED where it applies (k <= 2, no stress, shuffle solver),
-                                      else SLOTS */
+#define EQLB_SCATTER_AUTO (-1)     /* default: TILED where it applies (k <= 3 with the shuffle solver; stress:
+                                      RT_2 without flux BCs on the stress rows), else SLOTS */
 #define EQLB_SCATTER_TILED 2       /* one workgroup per tile of cells: vertex contributions summed in
                                       LDS in fixed order, no slot buffer (plain flux equilibration) */
 

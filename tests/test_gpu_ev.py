@@ -128,9 +128,9 @@ def test_ev_golden(name):
     assert _close(eq.equilibrate_host(G, f), expected)
 
 
-@pytest.mark.parametrize("k", [1, 2])
+@pytest.mark.parametrize("k", [1, 2, 3])
 def test_ev_tiled_is_bitwise_the_slot_path(oracle_mod, k):
-    """EV on the tiled launch (default for k <= 2): conforming flush by facet owner."""
+    """EV on the tiled launch (the default): conforming flush by facet owner."""
     from dolfinx_eqlb_amd import cpp
     mesh, ft, G, f = make_case(20, k, "neumann_lt")
     cd, nd = conforming_dofmap(mesh, k)
