@@ -168,7 +168,10 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   // (sub == 1, sub < n, ... for every P) out of the wave-block loops of the kernel, where they occupy
   // registers across all bins - that kernel sits at its 128-VGPR budget and would spill (the SE kernel
   // fits and is 1 % faster with the hoisted predicates)
-  if constexpr (SCATTER == 2 && MODE == 1)
+#ifndef EQLB_OPAQUE_K3
+#define EQLB_OPAQUE_K3 1 // RT_3 tiled: 219 -> 207 VGPRs, 0.345 -> 0.338 ms at 1M triangles
+#endif
+  if constexpr (SCATTER == 2 && (MODE == 1 || (EQLB_OPAQUE_K3 && K >= 3)))
     asm volatile("" : "+v"(tid_));
   const int tid = tid_;
   if (!tables_staged)

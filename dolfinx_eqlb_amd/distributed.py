@@ -1,26 +1,174 @@
-"""Multi-GPU decomposition of the patch loop: node-ownership strips + reverse halo reduction.
+"""Multi-GPU decomposition of the patch loop: node ownership + reverse halo reduction.
 
 The reference has no distributed equilibration (its node loop runs over
 index_map(0)->size_local() owned nodes, se/reconstruction.hpp:90,286, and the flux of ghost
 cells is never reduced, FluxEqlbSE.py:164 "TODO").  Design here: patches are
 independent and partitioned by node ownership; every cell's RT DOFs receive exactly one
 contribution per vertex patch (se/solve_patch_semiexplt.hpp:1157-1160), so the only exchange
-is the ADDITION of the partial sums a rank computed for cells owned by a neighbour.  With
-strips along x each rank has at most two neighbours: point-to-point send/recv over xGMI
-(torch.distributed NCCL backend == RCCL), no collective on the data path.
+is the ADDITION of the partial sums a rank computed for cells (or conforming DOFs) owned by a
+neighbour: point-to-point send/recv over xGMI (torch.distributed NCCL backend == RCCL), no
+collective on the data path.
 
-Strip r owns the squares with column index in [r n, (r+1) n) of a (world n) x n crossed grid on
-[0, world] x [0, 1] and the nodes with x in (r, r+1] (x = 0 included for r = 0).  Its local
-mesh also holds the 3 n ghost triangles of strip r+1 that touch its right interface nodes;
-after the local sweep their rows are sent to rank r+1 and added there.
+Two producers of a decomposition share one interface (mesh, node_mask, cell_owned, send / recv
+lists per peer):
+
+  Partition       any mesh, any (node owner, cell owner) pair - the ownership-driven loop of the
+                  reference for an arbitrary DOLFINx partition; built from the GLOBAL mesh.
+  StripPartition  the benchmark's strips of a crossed rectangle, built WITHOUT the global mesh
+                  (8M triangles per node would not be replicated on every rank).
+
+A rank's local mesh holds every cell with a vertex it owns: its own cells plus the ghost cells
+(owned by the rank that owns their highest-ranked vertex) its boundary patches reach into.
 """
 
 import numpy as np
 
-from .mesh import create_rectangle
+from .mesh import create_mesh, create_rectangle
+
+
+def _patch_cells_per_bin(mesh, node_mask):
+    """Number of (patch, cell) pairs handled by the kernel launch of each lane-group bin
+    (P = 4, 8, 16, 32, 64 >= number of patch facets)."""
+    nc = np.diff(mesh.node_cells_offsets)
+    nf = np.diff(mesh.node_facets_offsets)
+    sel = np.ones(mesh.nnodes, dtype=bool) if node_mask is None else node_mask.astype(bool)
+    out = []
+    lo = 0
+    for P in (4, 8, 16, 32, 64):
+        inbin = sel & (nf > lo) & (nf <= P)
+        out.append(int(nc[inbin].sum()))
+        lo = P
+    return out
+
+
+class Partition:
+    """Decomposition of an arbitrary mesh by node ownership.
+
+    node_owner [nnodes]: rank that equilibrates the patch of each node; cell_owner [ncells]
+    (default: the highest owner among the cell's vertices): rank that holds the final RT DOFs of
+    the cell.  Local cells keep the local vertex order of the global mesh, so shared cells agree
+    on every rank.  send[q] / recv[q]: local cell ids whose rows go to / arrive from rank q, both
+    ordered by global cell id."""
+
+    def __init__(self, gmesh, node_owner, rank: int, world: int, cell_owner=None):
+        node_owner = np.asarray(node_owner)
+        self.rank, self.world = rank, world
+        vo = node_owner[gmesh.cell_nodes]                      # [ncells, 3]
+        if cell_owner is None:
+            cell_owner = vo.max(axis=1)
+        cell_owner = np.asarray(cell_owner)
+        if np.any((cell_owner[:, None] != vo).all(axis=1)):
+            raise RuntimeError("Partition: a cell must be owned by the owner of one of its vertices")
+        local = np.nonzero((vo == rank).any(axis=1))[0]        # cells reached by this rank's patches
+        self.cell_global = local
+        gnodes = np.unique(gmesh.cell_nodes[local])
+        self.node_global = gnodes
+        g2l = -np.ones(gmesh.nnodes, dtype=np.int64)
+        g2l[gnodes] = np.arange(gnodes.size)
+        self.mesh = create_mesh(gmesh.x[gnodes, :2], g2l[gmesh.cell_nodes[local]].astype(np.int32))
+        self.cell_owned = cell_owner[local] == rank
+        self.ncells_owned = int(self.cell_owned.sum())
+        mask = (node_owner[gnodes] == rank).astype(np.uint8)
+        self.node_mask = None if world == 1 else mask
+        # halo lists: my ghost cells go to their owner; the owner finds them among ITS cells that have
+        # a vertex of mine (same rule evaluated from the other side), both sides sorted by global id
+        self.send, self.recv = {}, {}
+        for q in range(world):
+            if q == rank:
+                continue
+            s = np.nonzero(cell_owner[local] == q)[0]
+            if s.size:
+                self.send[q] = s.astype(np.int64)
+            r = np.nonzero((cell_owner[local] == rank) & (vo[local] == q).any(axis=1))[0]
+            if r.size:
+                self.recv[q] = r.astype(np.int64)
+        # facets of the global mesh -> local facets (for boundary data given on the global mesh)
+        self._gmesh_nfacets = gmesh.nfacets
+        key_g = gmesh.facet_nodes[:, 0].astype(np.int64) * gmesh.nnodes + gmesh.facet_nodes[:, 1]
+        lf = gnodes[self.mesh.facet_nodes]                      # global node ids of the local facets
+        key_l = np.minimum(lf[:, 0], lf[:, 1]).astype(np.int64) * gmesh.nnodes + np.maximum(lf[:, 0], lf[:, 1])
+        order = np.argsort(key_g)
+        self.facet_global = order[np.searchsorted(key_g[order], key_l)]
+        # conforming DOFs (EV): a facet is owned by the highest owner of its cells and HELD by every rank
+        # that owns a vertex of one of its cells (those ranks have it in their local mesh)
+        off = gmesh.facet_cells_offsets
+        c0 = gmesh.facet_cells[off[:-1]]
+        c1 = gmesh.facet_cells[np.minimum(off[:-1] + 1, off[1:] - 1)]  # == c0 on boundary facets
+        self._facet_owner = np.maximum(cell_owner[c0], cell_owner[c1])[self.facet_global]
+        self._facet_holders = np.concatenate([vo[c0], vo[c1]], axis=1)[self.facet_global]  # [nf_local, 6]
+        self._cell_owner_l = cell_owner[local]
+        self._cell_holders = vo[local]
+
+    @property
+    def send_cells(self):
+        """All ghost cells (priority cells of the two-phase sweep)."""
+        return np.concatenate([v for _, v in sorted(self.send.items())]) if self.send else np.zeros(0, np.int64)
+
+    def facet_types(self, global_facet_type):
+        """facet_type table of the local mesh from the one of the global mesh [nrhs, nfacets]; the
+        artificial boundary facets of the ghost layer (interior facets of the global mesh) only touch
+        nodes this rank does not own and are marked as primal-Dirichlet facets."""
+        gft = np.asarray(global_facet_type).reshape(-1, self._gmesh_nfacets)
+        ft = gft[:, self.facet_global].astype(np.int8)
+        artificial = np.zeros(self.mesh.nfacets, dtype=bool)
+        artificial[self.mesh.boundary_facets()] = True
+        artificial &= gft[0, self.facet_global] == 0
+        ft[:, artificial] = 1
+        return ft
+
+    def patch_cells_per_bin(self):
+        return _patch_cells_per_bin(self.mesh, self.node_mask)
+
+    def conforming_halo(self, k):
+        """Halo lists of the conforming RT_k DOFs (EV equilibrator, default numbering of
+        eqlb/conforming.py): (send, recv) dicts of local DOF indices per peer, matching order (global
+        facet id, then global cell id).  Every rank that holds a facet computes a partial value for its
+        DOFs; the partial values are sent to the facet's owner (highest owner among its cells) and
+        added there; interior DOFs travel with their cell."""
+        m, r = self.mesh, self.rank
+        ni = k * k - k
+        jf = np.arange(k, dtype=np.int64)
+        ji = np.arange(ni, dtype=np.int64)
+        f_order = np.argsort(self.facet_global)
+        c_order = np.argsort(self.cell_global)
+        send, recv = {}, {}
+        for q in range(self.world):
+            if q == r:
+                continue
+            fs = f_order[(self._facet_owner == q)[f_order]]
+            cs = c_order[(self._cell_owner_l == q)[c_order]]
+            d = np.concatenate([(fs[:, None] * k + jf).ravel(),
+                                (m.nfacets * k + cs[:, None] * ni + ji).ravel()]).astype(np.int64)
+            if d.size:
+                send[q] = d
+            fr = f_order[((self._facet_owner == r) & (self._facet_holders == q).any(axis=1))[f_order]]
+            cr = c_order[((self._cell_owner_l == r) & (self._cell_holders == q).any(axis=1))[c_order]]
+            d = np.concatenate([(fr[:, None] * k + jf).ravel(),
+                                (m.nfacets * k + cr[:, None] * ni + ji).ravel()]).astype(np.int64)
+            if d.size:
+                recv[q] = d
+        return send, recv
+
+
+def _conforming_halo(mesh, k, send, recv):
+    from .eqlb.conforming import conforming_dofmap
+    cd, _ = conforming_dofmap(mesh, k)
+
+    def dofs(cells):
+        # per cell the same local DOF order on both sides; a facet shared by two cells of the list appears
+        # twice - at the same positions on both sides - and is kept once (first occurrence)
+        d = cd[cells].reshape(-1).astype(np.int64)
+        first = np.sort(np.unique(d, return_index=True)[1])
+        return d[first]
+    return {q: dofs(c) for q, c in send.items()}, {q: dofs(c) for q, c in recv.items()}
 
 
 class StripPartition:
+    """Strip r owns the squares with column index in [r n, (r+1) n) of a (world n) x n crossed grid
+    on [0, world] x [0, 1] and the nodes with x in (r, r+1] (x = 0 included for r = 0).  Its local
+    mesh also holds the 3 n ghost triangles of strip r+1 that touch its right interface nodes;
+    after the local sweep their rows are sent to rank r+1 and added there."""
+
     def __init__(self, n: int, rank: int = 0, world: int = 1, shuffle_seed=None):
         self.n, self.rank, self.world = n, rank, world
         ghost = 1 if rank < world - 1 else 0
@@ -54,12 +202,15 @@ class StripPartition:
         order = np.lexsort((gt, gj))
         self.send_cells = np.zeros(0, dtype=np.int64)  # ghost cells -> rank + 1
         self.recv_cells = np.zeros(0, dtype=np.int64)  # own first column <- rank - 1
+        self.send, self.recv = {}, {}
         if ghost:
             sel = order[(gi == n)[order]]
             self.send_cells = sel.astype(np.int64)
+            self.send[rank + 1] = self.send_cells
         if rank > 0:
             sel = order[((gi == 0) & (gt != 1))[order]]
             self.recv_cells = sel.astype(np.int64)
+            self.recv[rank - 1] = self.recv_cells
 
     def facet_types(self, nrhs: int = 1):
         """Homogeneous Dirichlet on every boundary facet of the local mesh (the artificial
@@ -69,65 +220,71 @@ class StripPartition:
         return ft
 
     def patch_cells_per_bin(self):
-        """Number of (patch, cell) pairs handled by the kernel launch of each lane-group bin
-        (P = 4, 8, 16, 32, 64 >= number of patch facets)."""
-        m = self.mesh
-        nc = np.diff(m.node_cells_offsets)
-        nf = np.diff(m.node_facets_offsets)
-        sel = np.ones(m.nnodes, dtype=bool) if self.node_mask is None else self.node_mask.astype(bool)
-        out = []
-        lo = 0
-        for P in (4, 8, 16, 32, 64):
-            inbin = sel & (nf > lo) & (nf <= P)
-            out.append(int(nc[inbin].sum()))
-            lo = P
-        return out
+        return _patch_cells_per_bin(self.mesh, self.node_mask)
+
+    def conforming_halo(self, k):
+        return _conforming_halo(self.mesh, k, self.send, self.recv)
 
 
 class HaloExchange:
-    """Reverse halo reduction of the ghost-cell rows of the RT coefficient vector."""
+    """Reverse halo reduction: rows (RT DOFs of ghost cells, `width` values per entry) or scalar
+    conforming DOFs (width = 1) are gathered, sent to their owner, added there and cleared here.
 
-    def __init__(self, part: StripPartition, nrt: int, device, nrhs: int = 1):
+    part: Partition / StripPartition (rows of the ghost cells), or explicit lists through `lists` =
+    (send, recv) dicts of index arrays per peer with `nentries` = number of rows of the vector
+    (EV: the conforming DOF lists of `part.conforming_halo(k)`)."""
+
+    def __init__(self, part, width: int, device, nrhs: int = 1, lists=None, nentries=None):
         import torch
-        self.part, self.nrt, self.nrhs = part, nrt, nrhs
-        self.send_idx = torch.from_numpy(part.send_cells).to(device)
-        self.recv_idx = torch.from_numpy(part.recv_cells).to(device)
-        self.send_buf = torch.zeros((nrhs, part.send_cells.size, nrt), dtype=torch.float64, device=device)
-        self.recv_buf = torch.zeros((nrhs, part.recv_cells.size, nrt), dtype=torch.float64, device=device)
+        self.part, self.nrt, self.nrhs = part, width, nrhs
+        self.rank = part.rank
+        send, recv = (part.send, part.recv) if lists is None else lists
+        self.nentries = part.mesh.ncells if nentries is None else int(nentries)
+        self.peers = sorted(set(send) | set(recv))
+        self.send_idx, self.recv_idx, self.send_buf, self.recv_buf = {}, {}, {}, {}
+        for q in self.peers:
+            if q in send:
+                s = send[q]
+                self.send_idx[q] = torch.from_numpy(np.ascontiguousarray(s, dtype=np.int64)).to(device)
+                self.send_buf[q] = torch.zeros((nrhs, len(s), width), dtype=torch.float64, device=device)
+            if q in recv:
+                r = recv[q]
+                self.recv_idx[q] = torch.from_numpy(np.ascontiguousarray(r, dtype=np.int64)).to(device)
+                self.recv_buf[q] = torch.zeros((nrhs, len(r), width), dtype=torch.float64, device=device)
         self._ops = None
 
     def reduce(self, x):
-        """x: [nrhs * ncells * nrt] tensor; adds the neighbour's partial sums to the owned rows
+        """x: [nrhs * nentries * width] tensor; adds the neighbours' partial sums to the owned rows
         and clears the ghost rows (their content now lives on the owner).  Device tensors use the
-        two halo kernels of libeqlb_amd.so (one launch each) around the RCCL send/recv; CPU tensors
-        (gloo tests) use plain indexing."""
+        two halo kernels of libeqlb_amd.so (one launch per peer and direction) around the RCCL
+        send/recv; CPU tensors (gloo tests) use plain indexing."""
         return self.finish(x, self.start(x))
 
     def start(self, x):
         """First half: pack the ghost rows (final once the tiles that own them have run) and post
-        the send / receive.  Work enqueued on the current stream after this call overlaps the
+        the sends / receives.  Work enqueued on the current stream after this call overlaps the
         transfer; finish() orders the unpack behind it."""
         import torch
         import torch.distributed as dist
-        part = self.part
-        xv = x.view(self.nrhs, part.mesh.ncells, self.nrt)
+        xv = x.view(self.nrhs, self.nentries, self.nrt)
         on_gpu = x.is_cuda
-        ns, nr = int(part.send_cells.size), int(part.recv_cells.size)
         stream = torch.cuda.current_stream().cuda_stream if on_gpu else 0
-        ops = []
-        if ns:
+        for q, idx in self.send_idx.items():
+            buf = self.send_buf[q]
             if on_gpu:
                 from . import cpp
-                cpp.halo_pack(x.data_ptr(), self.send_idx.data_ptr(), self.send_buf.data_ptr(),
-                              self.nrhs, ns, self.nrt, part.mesh.ncells, True, stream)
+                cpp.halo_pack(x.data_ptr(), idx.data_ptr(), buf.data_ptr(), self.nrhs, idx.numel(), self.nrt,
+                              self.nentries, True, stream)
             else:
-                self.send_buf.copy_(xv[:, self.send_idx, :])
-                xv[:, self.send_idx, :] = 0.0
+                buf.copy_(xv[:, idx, :])
+                xv[:, idx, :] = 0.0
         if self._ops is None:  # the descriptors are reused: same buffers, same peers every step
-            if ns:
-                ops.append(dist.P2POp(dist.isend, self.send_buf, part.rank + 1))
-            if nr:
-                ops.append(dist.P2POp(dist.irecv, self.recv_buf, part.rank - 1))
+            ops = []
+            for q in self.peers:
+                if q in self.send_buf:
+                    ops.append(dist.P2POp(dist.isend, self.send_buf[q], q))
+                if q in self.recv_buf:
+                    ops.append(dist.P2POp(dist.irecv, self.recv_buf[q], q))
             self._ops = ops
         return dist.batch_isend_irecv(self._ops) if self._ops else []
 
@@ -135,18 +292,17 @@ class HaloExchange:
         """Second half: wait for the transfer (the current stream waits, not the host) and add the
         received partial sums to the owned rows."""
         import torch
-        part = self.part
         on_gpu = x.is_cuda
-        nr = int(part.recv_cells.size)
         for req in reqs:
             req.wait()
-        if nr:
+        for q, idx in self.recv_idx.items():
+            buf = self.recv_buf[q]
             if on_gpu:
                 from . import cpp
                 stream = torch.cuda.current_stream().cuda_stream
-                cpp.halo_unpack_add(x.data_ptr(), self.recv_idx.data_ptr(), self.recv_buf.data_ptr(),
-                                    self.nrhs, nr, self.nrt, part.mesh.ncells, stream)
+                cpp.halo_unpack_add(x.data_ptr(), idx.data_ptr(), buf.data_ptr(), self.nrhs, idx.numel(),
+                                    self.nrt, self.nentries, stream)
             else:
-                xv = x.view(self.nrhs, part.mesh.ncells, self.nrt)
-                xv[:, self.recv_idx, :] += self.recv_buf
+                xv = x.view(self.nrhs, self.nentries, self.nrt)
+                xv[:, idx, :] += buf
         return x

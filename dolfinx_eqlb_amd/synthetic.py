@@ -107,11 +107,14 @@ def neumann_hat_moments(mesh, ft_row, w, weight=None):
 
 
 def make_compatible_data(mesh, k, facet_type, degree_dg=None, seed=20241003, u_ext=None,
-                         grad_u_ext=None, f_ext=None, tol=1e-13, neumann_flux=None):
+                         grad_u_ext=None, f_ext=None, tol=1e-13, neumann_flux=None, node_map=None):
     """Returns (flux_dg [ncells*nd*2], rhs_dg [ncells*nd]) satisfying the orthogonality.
 
     Default: smooth-plus-random data (random DG perturbation, so jumps of G are arbitrary).
     With grad_u_ext/f_ext: G = -I_h(grad u_ext), f0 = I_h(f_ext) (interpolated fields).
+    node_map [nnodes]: identification of nodes (periodic data: node_map[i] = representative of node i);
+    the orthogonality then holds for the hat functions of the identified nodes, i.e. on every copy of
+    the mesh laid side by side (the strips of a multi-GPU run carry the same data).
     """
     degree_dg = k - 1 if degree_dg is None else degree_dg
     rng = np.random.default_rng(seed)
@@ -145,8 +148,10 @@ def make_compatible_data(mesh, k, facet_type, degree_dg=None, seed=20241003, u_e
     r_loc = np.einsum("cj,jn->cn", f0, Mfh) * adet[:, None]
     Gint = np.einsum("cjd,j->cd", G, mpsi) * adet[:, None]
     r_loc += np.einsum("cd,cnd->cn", Gint, ghat)
+    nmap = np.arange(nnodes) if node_map is None else np.asarray(node_map)
+    cn = nmap[mesh.cell_nodes]
     r = np.zeros(nnodes)
-    np.add.at(r, mesh.cell_nodes.ravel(), r_loc.ravel())
+    np.add.at(r, cn.ravel(), r_loc.ravel())
 
     # free nodes: not on a primal-Dirichlet facet (of RHS 0)
     ft = np.asarray(facet_type).reshape(-1, mesh.nfacets)[0]
@@ -154,10 +159,10 @@ def make_compatible_data(mesh, k, facet_type, degree_dg=None, seed=20241003, u_e
         # inhomogeneous flux BC (sigma_eq + G) . n = w . n: (f, hat_a) + (G, grad hat_a) = <w . n, hat_a>
         r -= neumann_hat_moments(mesh, ft, neumann_flux)
     fixed = np.zeros(nnodes, dtype=bool)
-    fixed[mesh.facet_nodes[ft == 1].ravel()] = True
+    fixed[nmap[mesh.facet_nodes[ft == 1].ravel()]] = True
+    fixed |= nmap != np.arange(nnodes)  # identified nodes are represented by their image
     free = np.nonzero(~fixed)[0]
 
-    cn = mesh.cell_nodes
     rows = np.repeat(cn, 3, axis=1).ravel()
     cols = np.tile(cn, (1, 3)).ravel()
     if degree_dg >= 1:

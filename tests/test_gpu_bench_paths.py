@@ -33,7 +33,7 @@ def test_bench_line_has_the_contract_fields():
 
 
 @pytest.mark.parametrize("rank,world,extra", [(0, 2, []), (1, 2, []), (3, 8, []), (0, 2, ["--stress"]),
-                                              (0, 2, ["--k", "3"])])
+                                              (0, 2, ["--k", "3"]), (1, 3, ["--ev"]), (0, 2, ["--ev", "--k", "3"])])
 def test_multi_gpu_host_path(rank, world, extra):
     out = _run(["tools/smoke_bench_world2.py", "--n", "100", "--steps", "3", "--warmup", "1"] + extra,
                env={"SMOKE_RANK": str(rank), "SMOKE_WORLD": str(world)})
@@ -42,3 +42,5 @@ def test_multi_gpu_host_path(rank, world, extra):
         assert d["n_gpus"] == world and d["scaling"] == "weak"
         if not extra:
             assert "behind the interior tiles" in d["config"]["partition"]
+        if "--ev" not in extra:
+            assert d["div_residual_rel"] < 1e-10  # rank 0 receives nothing: its owned rows are complete
