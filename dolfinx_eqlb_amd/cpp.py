@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = [
     "eqlb_se_check_status", "eqlb_ev_check_status",
     "eqlb_se_set_priority_cells", "eqlb_se_num_priority_tiles", "eqlb_se_equilibrate_tiles",
     "eqlb_se_equilibrate_lists", "eqlb_ev_equilibrate_lists", "eqlb_se_kornconst",
+    "eqlb_ev_set_basis_transform",
 ]
 
 _lib = None
@@ -259,6 +260,15 @@ class ConstrainedMinEquilibrator:
             cd = np.ascontiguousarray(cell_dofs, dtype=np.int32)
             assert cd.shape == (dmesh.mesh.ncells, self.nrt)
             _check(lib().eqlb_ev_set_dofmap(self._h, _hp(cd), C.c_int64(int(ndofs))))
+
+    def set_basis_transform(self, C=None, R=None):
+        """Change of basis of the conforming output (eqlb_ev_set_basis_transform): C [nrt, nrt], R [k, k]."""
+        c = None if C is None else np.ascontiguousarray(C, dtype=np.float64)
+        r = None if R is None else np.ascontiguousarray(R, dtype=np.float64)
+        if c is not None:
+            assert c.shape == (self.nrt, self.nrt) and (r is None or r.shape == (self.k, self.k))
+        _check(lib().eqlb_ev_set_basis_transform(self._h, _hp(c) if c is not None else None,
+                                                 _hp(r) if r is not None else None))
 
     @property
     def ndofs(self):

@@ -5,13 +5,36 @@
 #include "eqlb_internal.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <future>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 namespace
 {
 thread_local std::string g_error;
+
+// EQLB_PROFILE_SETUP=1: wall time of the set-up phases on stderr
+struct SetupTimer
+{
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  SetupTimer() : on(getenv("EQLB_PROFILE_SETUP") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  void lap(const char* what)
+  {
+    if (!on)
+      return;
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[eqlb setup] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
 
 int fail(int code, const char* fmt, ...)
 {
@@ -202,7 +225,36 @@ static int64_t rcb_cut_nodes(const TileItem* a, int64_t n, int64_t nl, RcbCtx& c
   return ncut;
 }
 
-void rcb_split(TileItem* a, int64_t n, int64_t ntile, int tc, RcbCtx& c)
+// pool of bisection contexts for the worker threads (a context is [nnodes]-sized)
+struct RcbPool
+{
+  const int32_t* cell_nodes;
+  int32_t nnodes;
+  std::mutex mtx;
+  std::vector<std::unique_ptr<RcbCtx>> free_list;
+  std::unique_ptr<RcbCtx> acquire()
+  {
+    {
+      std::lock_guard<std::mutex> g(mtx);
+      if (!free_list.empty())
+      {
+        auto c = std::move(free_list.back());
+        free_list.pop_back();
+        return c;
+      }
+    }
+    return std::unique_ptr<RcbCtx>(new RcbCtx{cell_nodes, std::vector<int64_t>(nnodes, -1), std::vector<int64_t>(nnodes, -1), 0});
+  }
+  void release(std::unique_ptr<RcbCtx> c)
+  {
+    std::lock_guard<std::mutex> g(mtx);
+    free_list.push_back(std::move(c));
+  }
+};
+
+// The subtrees are independent of one another (a context only remembers the nodes of ITS current cut), so
+// the upper levels hand their halves to other host threads: same tiles as the serial recursion.
+void rcb_split(TileItem* a, int64_t n, int64_t ntile, int tc, RcbPool& pool, RcbCtx* c, int depth)
 {
   if (ntile <= 1 || n <= tc)
     return;
@@ -220,12 +272,18 @@ void rcb_split(TileItem* a, int64_t n, int64_t ntile, int tc, RcbCtx& c)
   // the last levels decide the shape of the tiles: there the cut is chosen by what it costs - the
   // nodes it separates - not by the extent of the bounding box (which misleads on stretched cells:
   // boundary layers, polar meshes)
+  std::unique_ptr<RcbCtx> own;
   if (ntile <= 64)
   {
+    if (!c)
+    {
+      own = pool.acquire();
+      c = own.get();
+    }
     rcb_partition(a, n, nl, axis);
-    const int64_t c0 = rcb_cut_nodes(a, n, nl, c);
+    const int64_t c0 = rcb_cut_nodes(a, n, nl, *c);
     rcb_partition(a, n, nl, 1 - axis);
-    const int64_t c1 = rcb_cut_nodes(a, n, nl, c);
+    const int64_t c1 = rcb_cut_nodes(a, n, nl, *c);
     if (c1 < c0)
       axis = 1 - axis; // already partitioned along it
     else
@@ -233,8 +291,42 @@ void rcb_split(TileItem* a, int64_t n, int64_t ntile, int tc, RcbCtx& c)
   }
   else
     rcb_partition(a, n, nl, axis);
-  rcb_split(a, nl, tl, tc, c);
-  rcb_split(a + nl, n - nl, ntile - tl, tc, c);
+  constexpr int PAR_DEPTH = 5; // up to 32 concurrent subtrees
+  if (depth < PAR_DEPTH && n > 16 * (int64_t)tc)
+  {
+    // (a context taken above stays with this thread's half)
+    auto left = std::async(std::launch::async, [&]() { rcb_split(a, nl, tl, tc, pool, nullptr, depth + 1); });
+    rcb_split(a + nl, n - nl, ntile - tl, tc, pool, c, depth + 1);
+    left.get();
+  }
+  else
+  {
+    rcb_split(a, nl, tl, tc, pool, c, depth + 1);
+    rcb_split(a + nl, n - nl, ntile - tl, tc, pool, c, depth + 1);
+  }
+  if (own)
+    pool.release(std::move(own));
+}
+
+// f(i) for i in [0, n) on the host threads (contiguous chunks)
+template <typename F>
+void parallel_for(int64_t n, int64_t min_chunk, F f)
+{
+  const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(std::thread::hardware_concurrency(), n / std::max<int64_t>(min_chunk, 1)));
+  if (nt <= 1)
+  {
+    for (int64_t i = 0; i < n; ++i)
+      f(i);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int64_t t = 0; t < nt; ++t)
+    th.emplace_back([=]() {
+      for (int64_t i = n * t / nt; i < n * (t + 1) / nt; ++i)
+        f(i);
+    });
+  for (auto& x : th)
+    x.join();
 }
 
 // Tiled SoA of the plain flux equilibration (EQLB_SCATTER_TILED): cells bisected recursively by
@@ -269,9 +361,9 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
       TC = (int)(((int64_t)nc + rounds * slots - 1) / (rounds * slots));
     }
   }
+  SetupTimer tm;
   std::vector<TileItem> items(nc);
-  for (int32_t c = 0; c < nc; ++c)
-  {
+  parallel_for(nc, 1 << 16, [&](int64_t c) {
     const int32_t* cn = &m.h_cell_nodes[3 * (size_t)c];
     double cx = 0.0, cy = 0.0;
     for (int j = 0; j < 3; ++j)
@@ -279,15 +371,18 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
       cx += m.h_x[3 * (size_t)cn[j]];
       cy += m.h_x[3 * (size_t)cn[j] + 1];
     }
-    items[c] = {cx, cy, c};
-  }
+    items[c] = {cx, cy, (int32_t)c};
+  });
   const int32_t ntiles = (nc + TC - 1) / TC;
-  RcbCtx rctx{m.h_cell_nodes.data(), std::vector<int64_t>(m.nnodes, -1), std::vector<int64_t>(m.nnodes, -1), 0};
-  rcb_split(items.data(), nc, ntiles, TC, rctx);
+  RcbPool pool{m.h_cell_nodes.data(), m.nnodes, {}, {}};
+  tm.lap("tiles: centroids");
+  rcb_split(items.data(), nc, ntiles, TC, pool, nullptr, 0);
+  tm.lap("tiles: bisection");
   // ascending cell ids inside a tile: the flush of a tile then touches flux_hdiv in long runs
-  for (int32_t t = 0; t < ntiles; ++t)
+  parallel_for(ntiles, 16, [&](int64_t t) {
     std::sort(items.begin() + (size_t)t * TC, items.begin() + std::min<size_t>((size_t)(t + 1) * TC, nc),
               [](const TileItem& p, const TileItem& q) { return p.cell < q.cell; });
+  });
   // tiles that own a priority cell (ghost rows a neighbour rank waits for) are numbered first: a
   // first launch over them, the halo exchange, and the launch over the rest then overlap
   std::vector<int32_t> order(ntiles);
@@ -308,6 +403,7 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
       if (!tile_prio[t])
         order[np++] = t;
   }
+  tm.lap("tiles: sort + priority");
   std::vector<int32_t> tile_cells((size_t)ntiles * TC, -1), cell_tile(nc), cell_pos(nc);
   for (int32_t t = 0; t < ntiles; ++t)
   {
@@ -321,53 +417,99 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
     }
   }
   std::vector<eqlb::TileDesc> tiles(ntiles);
-  std::vector<int32_t> inst_node, inst_slot, inst_tile, stamp(m.nnodes, -1);
-  std::vector<int32_t> blist[eqlb::MAX_BINS];
-  int64_t slotctr = 0;
-  for (int32_t t = 0; t < ntiles; ++t)
-  {
-    for (auto& l : blist)
-      l.clear();
-    for (int q = 0; q < TC; ++q)
+  // pass 1 (host threads, a chunk of tiles each): the nodes of every tile by bin - full interior patches
+  // (as many cells as lanes, no boundary facet: their wave-blocks run the specialised body of the kernel)
+  // first -, in order of first appearance; flat storage, 3 TC entries per tile
+  constexpr int NB = eqlb::MAX_BINS;
+  std::vector<int32_t> tnodes((size_t)ntiles * 3 * TC);
+  std::vector<int32_t> tcount((size_t)ntiles * 2 * NB, 0); // [tile][bin][full, other]
+  auto tile_chunks = [&](auto work) {
+    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(std::thread::hardware_concurrency(), ntiles / 32));
+    if (nt <= 1)
     {
-      const int32_t c = tile_cells[(size_t)t * TC + q];
-      if (c < 0)
-        continue;
-      for (int j = 0; j < 3; ++j)
+      work(0, ntiles);
+      return;
+    }
+    std::vector<std::thread> th;
+    for (int64_t w = 0; w < nt; ++w)
+      th.emplace_back(work, (int64_t)ntiles * w / nt, (int64_t)ntiles * (w + 1) / nt);
+    for (auto& x : th)
+      x.join();
+  };
+  tile_chunks([&](int64_t t0, int64_t t1) {
+    std::vector<int32_t> stamp(m.nnodes, -1), seen(3 * (size_t)TC);
+    for (int64_t t = t0; t < t1; ++t)
+    {
+      int nseen = 0;
+      int32_t* cnt = &tcount[(size_t)t * 2 * NB];
+      auto key = [&](int32_t nd) {
+        const int b_ = node_bin[nd], Pb = eqlb::BIN_P[b_];
+        return 2 * b_ + ((m.h_node_ncells[nd] == Pb && m.h_node_nfcts[nd] == Pb) ? 0 : 1);
+      };
+      for (int q = 0; q < TC; ++q)
       {
-        const int32_t nd = m.h_cell_nodes[3 * (size_t)c + j];
-        if (node_bin[nd] < 0)
-          tiles[t].zero = 1; // masked-out vertex: the (cell, vertex) row of this tile stays unwritten
-        if (node_bin[nd] < 0 || stamp[nd] == t)
+        const int32_t c = tile_cells[(size_t)t * TC + q];
+        if (c < 0)
           continue;
-        stamp[nd] = t;
-        blist[node_bin[nd]].push_back(nd);
+        for (int j = 0; j < 3; ++j)
+        {
+          const int32_t nd = m.h_cell_nodes[3 * (size_t)c + j];
+          if (node_bin[nd] < 0)
+            tiles[t].zero = 1; // masked-out vertex: the (cell, vertex) row of this tile stays unwritten
+          if (node_bin[nd] < 0 || stamp[nd] == (int32_t)t)
+            continue;
+          stamp[nd] = (int32_t)t;
+          seen[nseen++] = nd;
+          ++cnt[key(nd)];
+        }
+      }
+      int32_t pos[2 * NB], acc = 0; // stable counting sort by (bin, full first)
+      for (int q = 0; q < 2 * NB; ++q)
+      {
+        pos[q] = acc;
+        acc += cnt[q];
+      }
+      int32_t* out = &tnodes[(size_t)t * 3 * TC];
+      for (int i = 0; i < nseen; ++i)
+        out[pos[key(seen[i])]++] = seen[i];
+      for (int b_ = 0; b_ < NB; ++b_)
+      {
+        tiles[t].nfull[b_] = cnt[2 * b_];
+        tiles[t].npatch[b_] = cnt[2 * b_] + cnt[2 * b_ + 1];
       }
     }
-    for (int b = 0; b < eqlb::MAX_BINS; ++b)
+  });
+  // lane slots and patch instances in tile order (serial prefix), then filled by the host threads
+  int64_t slotctr = 0, ninst = 0;
+  for (int32_t t = 0; t < ntiles; ++t)
+    for (int b_ = 0; b_ < NB; ++b_)
     {
-      // full interior patches (as many cells as lanes, no boundary facet) first: their wave-blocks
-      // run the specialised body of the kernel
-      const int Pb = eqlb::BIN_P[b];
-      const auto mid = std::stable_partition(blist[b].begin(), blist[b].end(), [&](int32_t nd) {
-        return m.h_node_ncells[nd] == Pb && m.h_node_nfcts[nd] == Pb;
-      });
-      tiles[t].nfull[b] = (int32_t)(mid - blist[b].begin());
-      tiles[t].slot_start[b] = (int32_t)slotctr;
-      tiles[t].patch_start[b] = (int32_t)inst_node.size();
-      tiles[t].npatch[b] = (int32_t)blist[b].size();
-      for (int32_t nd : blist[b])
-      {
-        inst_node.push_back(nd);
-        inst_slot.push_back((int32_t)slotctr);
-        inst_tile.push_back(t);
-        slotctr += eqlb::BIN_P[b];
-      }
+      tiles[t].slot_start[b_] = (int32_t)slotctr;
+      tiles[t].patch_start[b_] = (int32_t)ninst;
+      slotctr += (int64_t)tiles[t].npatch[b_] * eqlb::BIN_P[b_];
+      ninst += tiles[t].npatch[b_];
       slotctr = (slotctr + 63) & ~(int64_t)63;
       if (slotctr > 0x7fffff00)
         return fail(EQLB_ERR_UNSUPPORTED, "tiled patch SoA exceeds 2^31 lane slots");
     }
-  }
+  std::vector<int32_t> inst_node((size_t)ninst), inst_slot((size_t)ninst), inst_tile((size_t)ninst);
+  tile_chunks([&](int64_t t0, int64_t t1) {
+    for (int64_t t = t0; t < t1; ++t)
+    {
+      const int32_t* src = &tnodes[(size_t)t * 3 * TC];
+      for (int b_ = 0; b_ < NB; ++b_)
+      {
+        int32_t slot = tiles[t].slot_start[b_];
+        for (int32_t i = 0, p_ = tiles[t].patch_start[b_]; i < tiles[t].npatch[b_]; ++i, ++p_, slot += eqlb::BIN_P[b_])
+        {
+          inst_node[p_] = *src++;
+          inst_slot[p_] = slot;
+          inst_tile[p_] = (int32_t)t;
+        }
+      }
+    }
+  });
+  tm.lap("tiles: patch lists");
   h->ntiles = ntiles;
   h->tile_tc = TC;
   h->t_nslots = slotctr;
@@ -413,6 +555,7 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
     if (e == hipSuccess)
       e = hipDeviceSynchronize();
   }
+  tm.lap("tiles: upload + builder kernel");
   dfree(d_inode);
   dfree(d_islot);
   dfree(d_itile);
@@ -676,6 +819,7 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
 {
   if (!h || !facet_type)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_set_boundary: null argument");
+  SetupTimer tm;
   const eqlb::DeviceMesh& m = h->mesh->m;
   for (size_t i = 0; i < (size_t)h->nrhs * m.nfacets; ++i)
     if (facet_type[i] < EQLB_FACET_INTERNAL || facet_type[i] > EQLB_FACET_ESSNT_DUAL)
@@ -701,7 +845,9 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
     if (m.h_node_ncells[i] < 1)
       return fail(EQLB_ERR_INVALID_ARGUMENT, "node %d belongs to no cell", i);
   }
+  tm.lap("checks");
   free_boundary(h);
+  tm.lap("free old tables");
 
   // bins by lanes per patch: P = smallest of {4,8,16,32,64} >= number of patch facets
   std::vector<int64_t> node_slot(m.nnodes, -1), node_patch(m.nnodes, -1);
@@ -744,6 +890,7 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
     ++count[b];
   }
 
+  tm.lap("binning");
   int st = 0;
   st |= upload(&h->facet_type, facet_type, (size_t)h->nrhs * m.nfacets);
   if (inhomogeneous)
@@ -800,6 +947,7 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
   eqlb::launch_build_patches(a, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
+  tm.lap("plain SoA: upload + builder");
   h->t_stress = h->stress && h->k == 2 && !h->stress_flux_bcs && h->mode == 0;
   if (h->t_stress || (!h->stress && h->k <= 3))
   {
@@ -817,6 +965,7 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
       HIP_TRY(hipDeviceSynchronize());
     }
   }
+  tm.lap("tiles (total)");
   h->boundary_set = true;
   return EQLB_OK;
 }
@@ -1180,7 +1329,8 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
     {
       const double* sl = h->slots + (size_t)l * s_slot * 3;
       if (ev_conf)
-        eqlb::launch_ev_reduce(m, h->k, per, h->ev_cell_dofs, h->ev_ndofs, sl, d_x[l], accumulate, stream);
+        eqlb::launch_ev_reduce(m, h->k, per, h->ev_cell_dofs, h->ev_ndofs, sl, d_x[l], accumulate, h->ev_basis,
+                               (h->ev_basis && h->ev_basis_has_R) ? h->ev_basis + h->nrt * h->nrt : nullptr, stream);
       else if (eqlb::launch_reduce_slots(h->nrt, m.ncells, per, sl, d_x[l], accumulate, stream))
         return fail(EQLB_ERR_UNSUPPORTED, "slot reduction for %d DOFs per cell is not in this build", h->nrt);
     }
@@ -1201,7 +1351,8 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
                                                : std::min(h->tile_count, h->ntiles - h->tile_first);
     eqlb::TileArgs ta{h->t_tiles, h->t_tile_cells, tcount, h->tile_tc,
                       ev_conf ? h->t_facet_owner : nullptr, h->ev_cell_dofs, h->ev_ndofs, m.nfacets,
-                      h->tile_first, h->accumulate};
+                      h->tile_first, h->accumulate, ev_conf ? h->ev_basis : nullptr,
+                      (ev_conf && h->ev_basis && h->ev_basis_has_R) ? h->ev_basis + h->nrt * h->nrt : nullptr};
     eqlb::SeArgs at = a;
     at.slot_cell = h->t_slot_cell;
     at.slot_info = h->t_slot_info;
@@ -1590,6 +1741,7 @@ void eqlb_ev_destroy(eqlb_ev_t* h)
   if (h->se)
   {
     dfree(h->se->ev_cell_dofs);
+    dfree(h->se->ev_basis);
     eqlb_se_destroy(h->se);
   }
   delete h;
@@ -1639,6 +1791,93 @@ int eqlb_ev_set_dofmap(eqlb_ev_t* h, const int32_t* cell_dofs, int64_t ndofs)
   return EQLB_OK;
 }
 
+int eqlb_ev_set_basis_transform(eqlb_ev_t* h, const double* C, const double* R)
+{
+  if (!h)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_ev_set_basis_transform: null argument");
+  eqlb_se* se = h->se;
+  dfree(se->ev_basis);
+  se->ev_basis_has_R = false;
+  if (!C)
+    return EQLB_OK;
+  const int nrt = se->nrt, k = se->k;
+  // facet rows of C must not see anything but their own facet block (the other functions of the
+  // hierarchic element have no normal trace there): the two cells of a facet would disagree otherwise
+  for (int f = 0; f < 3; ++f)
+    for (int j = 0; j < k; ++j)
+      for (int c = 0; c < nrt; ++c)
+        if ((c < f * k || c >= (f + 1) * k) && C[(f * k + j) * nrt + c] != 0.0)
+          return fail(EQLB_ERR_INVALID_ARGUMENT,
+                      "eqlb_ev_set_basis_transform: facet DOF %d of the target element depends on DOF %d outside its "
+                      "facet", f * k + j, c);
+  // [C | R | facet maps]: broken facet DOFs = (facet block of C)^-1 [R^-1] x target facet DOFs, for the boundary values
+  std::vector<double> buf((size_t)nrt * nrt + k * k + 6 * k * k, 0.0);
+  std::copy(C, C + (size_t)nrt * nrt, buf.begin());
+  double* Rd = buf.data() + (size_t)nrt * nrt;
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j)
+      Rd[i * k + j] = R ? R[i * k + j] : (i == j ? 1.0 : 0.0);
+  auto invert = [k](const double* A, double* Ai) -> bool { // Gauss-Jordan with partial pivoting, k <= 4
+    double w[4][8];
+    for (int i = 0; i < k; ++i)
+      for (int j = 0; j < k; ++j)
+      {
+        w[i][j] = A[i * k + j];
+        w[i][k + j] = (i == j) ? 1.0 : 0.0;
+      }
+    for (int c = 0; c < k; ++c)
+    {
+      int p = c;
+      for (int r = c + 1; r < k; ++r)
+        if (std::fabs(w[r][c]) > std::fabs(w[p][c]))
+          p = r;
+      if (w[p][c] == 0.0)
+        return false;
+      for (int j = 0; j < 2 * k; ++j)
+        std::swap(w[c][j], w[p][j]);
+      const double ip = 1.0 / w[c][c];
+      for (int j = 0; j < 2 * k; ++j)
+        w[c][j] *= ip;
+      for (int r = 0; r < k; ++r)
+        if (r != c)
+        {
+          const double f_ = w[r][c];
+          for (int j = 0; j < 2 * k; ++j)
+            w[r][j] -= f_ * w[c][j];
+        }
+    }
+    for (int i = 0; i < k; ++i)
+      for (int j = 0; j < k; ++j)
+        Ai[i * k + j] = w[i][k + j];
+    return true;
+  };
+  double Ri[16], Cf[16], Cfi[16];
+  if (!invert(Rd, Ri))
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_ev_set_basis_transform: R is singular");
+  double* maps = Rd + k * k;
+  for (int f = 0; f < 3; ++f)
+  {
+    for (int i = 0; i < k; ++i)
+      for (int j = 0; j < k; ++j)
+        Cf[i * k + j] = C[(f * k + i) * nrt + f * k + j];
+    if (!invert(Cf, Cfi))
+      return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_ev_set_basis_transform: facet block %d of C is singular", f);
+    for (int i = 0; i < k; ++i)
+      for (int j = 0; j < k; ++j)
+      {
+        maps[((f * 2 + 0) * k + i) * k + j] = Cfi[i * k + j];
+        double a_ = 0.0;
+        for (int q = 0; q < k; ++q)
+          a_ += Cfi[i * k + q] * Ri[q * k + j];
+        maps[((f * 2 + 1) * k + i) * k + j] = a_;
+      }
+  }
+  if (upload(&se->ev_basis, buf.data(), buf.size()))
+    return EQLB_ERR_DEVICE;
+  se->ev_basis_has_R = R != nullptr;
+  return EQLB_OK;
+}
+
 int64_t eqlb_ev_num_dofs(const eqlb_ev_t* h) { return h ? h->se->ev_ndofs : 0; }
 
 int eqlb_ev_set_boundary(eqlb_ev_t* h, const int8_t* facet_type, const double* boundary_values,
@@ -1669,8 +1908,8 @@ int eqlb_ev_set_boundary(eqlb_ev_t* h, const int8_t* facet_type, const double* b
     hipError_t e = hipMemset(se->bvals, 0, sizeof(double) * (size_t)se->nrhs * m.ncells * se->nrt);
     if (e == hipSuccess)
     {
-      eqlb::launch_ev_boundary_to_broken(m, se->k, se->nrhs, se->ev_cell_dofs, se->ev_ndofs, d_conf,
-                                         se->bvals, nullptr);
+      eqlb::launch_ev_boundary_to_broken(m, se->k, se->nrhs, se->ev_cell_dofs, se->ev_ndofs, d_conf, se->bvals,
+                                         se->ev_basis ? se->ev_basis + se->nrt * se->nrt + se->k * se->k : nullptr, nullptr);
       e = hipDeviceSynchronize();
     }
     dfree(d_conf);

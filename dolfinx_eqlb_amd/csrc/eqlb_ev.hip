@@ -40,7 +40,8 @@ template <int K>
 __global__ void __launch_bounds__(256)
 k_ev_boundary_to_broken(int32_t ncells, int32_t nfacets, int nrhs, const int32_t* cell_facets,
                         const uint8_t* facet_perm, const int32_t* cell_dofs, int64_t ndofs,
-                        const double* __restrict__ bv_conf, double* __restrict__ bv_broken)
+                        const double* __restrict__ bv_conf, double* __restrict__ bv_broken,
+                        const double* __restrict__ facet_maps)
 {
   constexpr int NRT = K * (K + 2);
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -54,7 +55,22 @@ k_ev_boundary_to_broken(int32_t ncells, int32_t nfacets, int nrhs, const int32_t
 #pragma unroll
   for (int j = 0; j < K; ++j)
     g[j] = bv_conf[(int64_t)r * ndofs + conf_dof<K>(cell_dofs, cell_facets, nfacets, c, f * K + j)];
-  facet_map<K>(facet_perm[(int64_t)c * 3 + f] != 0, g, o);
+  const bool rev = facet_perm[(int64_t)c * 3 + f] != 0;
+  if (facet_maps)
+  {
+    const double* M = facet_maps + ((f * 2 + (rev ? 1 : 0)) * K) * K;
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+    {
+      double s_ = 0.0;
+#pragma unroll
+      for (int i = 0; i < K; ++i)
+        s_ += M[j * K + i] * g[i];
+      o[j] = s_;
+    }
+  }
+  else
+    facet_map<K>(rev, g, o);
 #pragma unroll
   for (int j = 0; j < K; ++j)
     bv_broken[((int64_t)r * ncells + c) * NRT + f * K + j] = o[j];
@@ -112,26 +128,102 @@ k_ev_reduce(int32_t ncells, int32_t nfacets, int nrhs, const int32_t* cell_facet
   }
 }
 
+// the same reduction into another element basis of RT_k (eqlb_ev_set_basis_transform): one thread per cell
+template <int K>
+__global__ void __launch_bounds__(256)
+k_ev_reduce_basis(int32_t ncells, int32_t nfacets, int nrhs, const int32_t* cell_facets,
+                  const uint8_t* facet_perm, const int32_t* facet_cells_off, const int32_t* facet_cells,
+                  const int32_t* cell_dofs, int64_t ndofs, const double* __restrict__ slots,
+                  double* __restrict__ x, int accumulate, const double* __restrict__ C,
+                  const double* __restrict__ R)
+{
+  constexpr int NRT = K * (K + 2), NI = K * K - K;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)ncells * nrhs)
+    return;
+  const int r = (int)(t / ncells);
+  const int32_t c = (int32_t)(t - (int64_t)r * ncells);
+  const double* s = slots + ((int64_t)r * ncells + c) * 3 * NRT;
+  double* xr = x + (int64_t)r * ndofs;
+  double v[NRT], y[NRT];
+#pragma unroll
+  for (int i = 0; i < NRT; ++i)
+    v[i] = (s[i] + s[NRT + i]) + s[2 * NRT + i];
+#pragma unroll
+  for (int i = 0; i < NRT; ++i)
+  {
+    double a = 0.0;
+#pragma unroll
+    for (int j = 0; j < NRT; ++j)
+      a += C[i * NRT + j] * v[j];
+    y[i] = a;
+  }
+#pragma unroll
+  for (int lf = 0; lf < 3; ++lf)
+  {
+    const int32_t fct = cell_facets[(int64_t)c * 3 + lf];
+    if (facet_cells[facet_cells_off[fct]] != c)
+      continue; // the first cell of the facet writes its DOFs
+    const bool rev = facet_perm[(int64_t)c * 3 + lf] != 0 && R != nullptr;
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+    {
+      double g = y[lf * K + j];
+      if (rev)
+      {
+        g = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+          g += R[j * K + i] * y[lf * K + i];
+      }
+      double* px = xr + conf_dof<K>(cell_dofs, cell_facets, nfacets, c, lf * K + j);
+      *px = accumulate ? *px + g : g;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+  {
+    double* px = xr + conf_dof<K>(cell_dofs, cell_facets, nfacets, c, 3 * K + i);
+    *px = accumulate ? *px + y[3 * K + i] : y[3 * K + i];
+  }
+}
+
 void launch_ev_boundary_to_broken(const DeviceMesh& m, int k, int nrhs, const int32_t* cell_dofs,
                                   int64_t ndofs, const double* bv_conf, double* bv_broken,
-                                  hipStream_t stream)
+                                  const double* facet_maps, hipStream_t stream)
 {
   const int64_t n = (int64_t)nrhs * m.ncells * 3;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   if (k == 1)
     hipLaunchKernelGGL(k_ev_boundary_to_broken<1>, grid, block, 0, stream, m.ncells, m.nfacets, nrhs,
-                       m.cell_facets, m.facet_perm, cell_dofs, ndofs, bv_conf, bv_broken);
+                       m.cell_facets, m.facet_perm, cell_dofs, ndofs, bv_conf, bv_broken, facet_maps);
   else if (k == 2)
     hipLaunchKernelGGL(k_ev_boundary_to_broken<2>, grid, block, 0, stream, m.ncells, m.nfacets, nrhs,
-                       m.cell_facets, m.facet_perm, cell_dofs, ndofs, bv_conf, bv_broken);
+                       m.cell_facets, m.facet_perm, cell_dofs, ndofs, bv_conf, bv_broken, facet_maps);
   else
     hipLaunchKernelGGL(k_ev_boundary_to_broken<3>, grid, block, 0, stream, m.ncells, m.nfacets, nrhs,
-                       m.cell_facets, m.facet_perm, cell_dofs, ndofs, bv_conf, bv_broken);
+                       m.cell_facets, m.facet_perm, cell_dofs, ndofs, bv_conf, bv_broken, facet_maps);
 }
 
 void launch_ev_reduce(const DeviceMesh& m, int k, int nrhs, const int32_t* cell_dofs, int64_t ndofs,
-                      const double* slots, double* x, int accumulate, hipStream_t stream)
+                      const double* slots, double* x, int accumulate, const double* basis_C, const double* basis_R,
+                      hipStream_t stream)
 {
+  if (basis_C)
+  {
+    const int64_t nt = (int64_t)m.ncells * nrhs;
+    const dim3 g2((unsigned)((nt + 255) / 256)), b2(256);
+    if (k == 1)
+      hipLaunchKernelGGL(k_ev_reduce_basis<1>, g2, b2, 0, stream, m.ncells, m.nfacets, nrhs, m.cell_facets, m.facet_perm,
+                         m.facet_cells_off, m.facet_cells, cell_dofs, ndofs, slots, x, accumulate, basis_C, basis_R);
+    else if (k == 2)
+      hipLaunchKernelGGL(k_ev_reduce_basis<2>, g2, b2, 0, stream, m.ncells, m.nfacets, nrhs, m.cell_facets, m.facet_perm,
+                         m.facet_cells_off, m.facet_cells, cell_dofs, ndofs, slots, x, accumulate, basis_C, basis_R);
+    else
+      hipLaunchKernelGGL(k_ev_reduce_basis<3>, g2, b2, 0, stream, m.ncells, m.nfacets, nrhs, m.cell_facets, m.facet_perm,
+                         m.facet_cells_off, m.facet_cells, cell_dofs, ndofs, slots, x, accumulate, basis_C, basis_R);
+    return;
+  }
   const int ni = k * k - k;
   const int64_t n = ((int64_t)m.nfacets + (int64_t)m.ncells * ni) * nrhs;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);

@@ -114,6 +114,10 @@ struct TileArgs
   int32_t nfacets;
   int32_t tile_first; // this launch handles the tiles [tile_first, tile_first + ntiles)
   int32_t accumulate; // 1: flux_hdiv += result (reference semantics), 0: flux_hdiv = result (no read of the old values)
+  // EV: change of basis of the conforming output (eqlb_ev_set_basis_transform) or nullptr (hierarchic RT_k):
+  // target cell DOFs = basis_C x broken hierarchic cell DOFs; basis_R: facet block of a reversed facet
+  const double* basis_C;
+  const double* basis_R;
 };
 
 struct BuildArgs
@@ -171,11 +175,13 @@ int stress_tile_cells();
 int launch_ev_patch_fused(int k, const SeArgs& a, const FusedBins& fb, hipStream_t stream);
 // conforming <-> broken layout of the EV equilibrator (eqlb_ev.hip); cell_dofs may be nullptr
 // (default numbering: facet*k + j, then nfacets*k + cell*(k^2-k) + i)
+// facet_maps: nullptr (hierarchic RT_k: -I / B) or [3][2][k][k]: broken facet DOFs = map[lf][reversed] x conforming ones
 void launch_ev_boundary_to_broken(const DeviceMesh& m, int k, int nrhs, const int32_t* cell_dofs,
                                   int64_t ndofs, const double* bv_conf, double* bv_broken,
-                                  hipStream_t stream);
+                                  const double* facet_maps, hipStream_t stream);
 void launch_ev_reduce(const DeviceMesh& m, int k, int nrhs, const int32_t* cell_dofs, int64_t ndofs,
-                      const double* slots, double* x, int accumulate, hipStream_t stream);
+                      const double* slots, double* x, int accumulate, const double* basis_C, const double* basis_R,
+                      hipStream_t stream);
 int launch_reduce_slots(int nrt, int32_t ncells, int32_t nrhs, const double* slots, double* x, int accumulate,
                         hipStream_t stream);
 int projection_matrix_host(int degree, int nq, const double* pts, const double* wts,
@@ -219,6 +225,8 @@ struct eqlb_se
   int ev_output = 0;                // EV: 0 conforming DOFs, 1 broken hierarchic RT_k layout
   int32_t* ev_cell_dofs = nullptr;  // EV: device copy of the caller's dofmap or nullptr (default)
   int64_t ev_ndofs = 0;             // EV: number of conforming flux DOFs
+  double* ev_basis = nullptr;       // EV: device copy of [C (nrt x nrt) | R (k x k) | facet maps 3 x 2 x k x k] or nullptr
+  bool ev_basis_has_R = false;
   bool stress_flux_bcs = true;       // some facet of stress row 0 / 1 carries a flux BC
   bool boundary_set = false;
   int64_t npatch_total = 0, nslots = 0;

@@ -1799,6 +1799,65 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
   }
   __syncthreads();
 
+  if (conforming && ta.basis_C != nullptr)
+  {
+    // conforming DOFs of ANOTHER element basis of RT_k (the Basix space of FluxEqlbEV.py:95-100 through a
+    // DOLFINx-side adapter): cell coefficients = C x broken hierarchic coefficients, facet block through R
+    // where the cell sees the facet reversed; facet DOFs by the first cell of the facet
+    constexpr int NI = K * K - K;
+    double* xc = a0.out + (int64_t)a0.rhs_out * ta.ndofs;
+    const int32_t* own = ta.facet_owner + (int64_t)tile * TC * 3;
+    for (int cl = threadIdx.x; cl < TC; cl += TILE_THREADS)
+    {
+      const int32_t cell = cells[cl];
+      if (cell < 0)
+        continue;
+      double c[NRT], y[NRT];
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+        c[i] = packed_sum<K, NPK>(sSlots + (int64_t)cl * 3 * NPK, i);
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+      {
+        double s_ = 0.0;
+#pragma unroll
+        for (int j = 0; j < NRT; ++j)
+          s_ += ta.basis_C[i * NRT + j] * c[j];
+        y[i] = s_;
+      }
+#pragma unroll
+      for (int lf = 0; lf < 3; ++lf)
+      {
+        const int32_t code = own[cl * 3 + lf];
+        if (code < 0)
+          continue;
+        const bool rev = (code & 1) != 0 && ta.basis_R != nullptr;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+        {
+          double g = y[lf * K + j];
+          if (rev)
+          {
+            g = 0.0;
+#pragma unroll
+            for (int i = 0; i < K; ++i)
+              g += ta.basis_R[j * K + i] * y[lf * K + i];
+          }
+          const int64_t dof = ta.cell_dofs ? (int64_t)ta.cell_dofs[(int64_t)cell * NRT + lf * K + j]
+                                           : (int64_t)(code >> 1) * K + j;
+          xc[dof] = ta.accumulate ? xc[dof] + g : g;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+      {
+        const int64_t dof = ta.cell_dofs ? (int64_t)ta.cell_dofs[(int64_t)cell * NRT + 3 * K + i]
+                                         : (int64_t)ta.nfacets * K + (int64_t)cell * NI + i;
+        xc[dof] = ta.accumulate ? xc[dof] + y[3 * K + i] : y[3 * K + i];
+      }
+    }
+    return;
+  }
   if (conforming)
   {
     // conforming DOFs (ev/solve_patch.hpp:223-227): facet DOFs by the first cell of the facet,

@@ -322,6 +322,19 @@ int eqlb_ev_set_option(eqlb_ev_t* handle, const char* key, int32_t value);
 int eqlb_ev_set_dofmap(eqlb_ev_t* handle, const int32_t* cell_dofs, int64_t ndofs);
 int64_t eqlb_ev_num_dofs(const eqlb_ev_t* handle);
 
+/* Element basis of the conforming output.  The reference scatters the EV flux into the Basix RT_k space
+ * through V_flux.dofmap (ev/solve_patch.hpp:223-227, FluxEqlbEV.py:95-100); without Basix the library
+ * writes the conforming hierarchic RT_k (above).  An adapter installs the change of basis here:
+ *   C [k(k+2)][k(k+2)] row-major: coefficients of a cell in the target element = C x its coefficients in the
+ *                      broken (cell-frame) hierarchic RT_k, C[i][j] = l_i^target(phi_j^hierarchic) on the
+ *                      reference cell; the facet rows may only involve the DOFs of their own facet;
+ *   R [k][k] or NULL   the target element's base transformation of a reflected edge: applied to the facet
+ *                      block of a cell whose facet_perm bit is set (NULL: none).
+ * Facet DOFs are written by the first cell of the facet; numbering by eqlb_ev_set_dofmap (or the default).
+ * Boundary values handed to eqlb_ev_set_boundary are then target-element DOFs as well.  C = NULL restores the
+ * hierarchic basis (equivalent to C = diag(-I facets, I interior), R = -B).  Call before eqlb_ev_set_boundary. */
+int eqlb_ev_set_basis_transform(eqlb_ev_t* handle, const double* C, const double* R);
+
 /* facet_type as eqlb_se_set_boundary; boundary_values [nrhs][ndofs] conforming boundary DOFs
  * (facet DOFs of the prescribed normal flux on the flux-BC facets, zero elsewhere) or NULL; the
  * per-patch values hat_a * g (base/BoundaryData.cpp:687-745) are formed in the kernel.

@@ -195,3 +195,61 @@ def test_fused_stress_launch_node_mask_and_accumulation(oracle_mod):
     assert np.array_equal(x1, full) and np.allclose(x2, 2 * x1, rtol=1e-14, atol=0)
     eq.set_option("accumulate", 0)
     assert np.array_equal(eq.equilibrate_host(G, f, np.full_like(x1, 3.0)), x1)
+
+
+# the 12 boundary layouts of python/test/unit/test_stressqlb_bcond.py:147-166: per side of the unit square
+# (x = 0, y = 0, x = 1, y = 1) whether stress row 0 / row 1 carries a flux (traction) condition
+BCOND_LAYOUTS = {
+    1: [[True, False], [False, False]], 2: [[False, True], [False, False]], 3: [[False, False], [False, True]],
+    4: [[False, False], [True, False]], 5: [[True, False], [False, True]], 6: [[True, False], [True, False]],
+    7: [[False, True], [False, True]], 8: [[False, True], [True, False]], 9: [[True, False], [True, True]],
+    10: [[False, True], [True, True]], 11: [[True, True], [False, True]], 12: [[True, True], [True, False]],
+}
+
+
+def _bcond_facet_types(mesh, layout):
+    """facet_type [2, nfacets]: sides 1, 2 (x = 0, y = 0) per the layout, sides 3, 4 primal Dirichlet."""
+    ft = np.zeros((2, mesh.nfacets), dtype=np.int8)
+    bf = mesh.boundary_facets()
+    mp = mesh.facet_midpoints()[bf]
+    ft[:, bf] = 1
+    side = [np.abs(mp[:, 0]) < 1e-12, np.abs(mp[:, 1]) < 1e-12]
+    for s in range(2):
+        for r in range(2):
+            if layout[s][r]:
+                ft[r, bf[side[s]]] = 2
+    return ft
+
+
+@pytest.mark.parametrize("id_bc", sorted(BCOND_LAYOUTS))
+@pytest.mark.parametrize("k", [2, 3])
+@pytest.mark.parametrize("n", [2, 5])
+def test_stress_boundary_layouts(oracle_mod, k, id_bc, n):
+    """Stress rows with DIFFERENT boundary types per row (mixed layouts of test_stressqlb_bcond.py): the
+    device path against the oracle on the reference's 2 x 2 crossed square and on a perturbed 5 x 5 one.
+    Where the reference's node order matters (overlapping groups of two-cell corner patches at RT_2 - the
+    reference's own expected failures 8, 10, 12 belong here) the library refuses; the oracle then either
+    refuses too or the case is skipped as 'outside this build'."""
+    from dolfinx_eqlb_amd import cpp
+    from dolfinx_eqlb_amd.mesh import create_unit_square
+    from dolfinx_eqlb_amd.synthetic import make_compatible_data
+    mesh = create_unit_square(n, shuffle_seed=None if n == 2 else 4, perturb=0.0 if n == 2 else 0.2)
+    ft = _bcond_facet_types(mesh, BCOND_LAYOUTS[id_bc])
+    rows = [make_compatible_data(mesh, k, ft[r:r + 1], seed=31 + r) for r in range(2)]
+    G = np.stack([r_[0] for r_ in rows])
+    f = np.stack([r_[1] for r_ in rows])
+    eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(mesh), k, 2, reconstruct_stress=True)
+    try:
+        eq.set_boundary(ft)
+    except RuntimeError as e:
+        assert "overlapping groups" in str(e) or "To many patches" in str(e)
+        pytest.skip("order-dependent grouped patches: " + str(e))
+    x = eq.equilibrate_host(G, f)
+    ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f, stress=True)
+    assert np.abs(x - ref).max() <= 1e-9 * np.abs(ref).max()
+    # row-wise conditions hold whatever the symmetry step does: divergence, jumps, flux BCs
+    from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
+    for r in range(2):
+        res, nrm = chk.divergence_residual(mesh, k, x[r], G[r], f[r])
+        assert res <= 1e-9 * nrm
+        assert chk.boundary_flux_residual(mesh, k, x[r], G[r], np.nonzero(ft[r] == 2)[0]) <= 1e-9 * np.abs(x).max()
