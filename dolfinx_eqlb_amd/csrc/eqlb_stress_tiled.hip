@@ -22,6 +22,9 @@
 //     mean-value multiplier is eliminated analytically: lambda = sum R / sum M, gamma_node := 0);
 //   * u_k = -A^-1 (B_k gamma) re-uses the multipliers of the cyclic reduction.
 #include "eqlb_device_common.h"
+#ifndef EQLB_STRESS_REPCR
+#define EQLB_STRESS_REPCR 0
+#endif
 
 namespace eqlb
 {
@@ -231,7 +234,8 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
     J11 = j1.y;
   }
   const double detJ = J00 * J11 - J01 * J10;
-  const double sgn = (detJ > 0.0) ? 1.0 : -1.0;
+  const bool neg_det = !(detJ > 0.0);
+  const double sgn = neg_det ? -1.0 : 1.0;
   const double pf_m = (fm == 1) ? sgn : -sgn, pf_p = (fp == 1) ? sgn : -sgn;
 
   // ---- neighbours ----
@@ -475,6 +479,9 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
   double am = dpp_d<0x111>(OffC);
   if (sub == 0)
     am = 0.0;
+  const double Dp_keep = Dp, am_keep = am;
+  (void)Dp_keep;
+  (void)am_keep;
   // chain reduction with the columns [load row 0 | load row 1 | column of d | column of x_0]; the
   // multipliers are kept for the columns of the weak-symmetry step
   double col4[4] = {in_chain ? rr[0] : 0.0, in_chain ? rr[1] : 0.0, B1, B2};
@@ -757,7 +764,15 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
       vd[k] = -(group_sum_d<P>(Bd[k] * gam_own, gbase, sub) + Bdc[k] * gam0);
     }
     double cu[2] = {in_chain ? vr[0] : 0.0, in_chain ? vr[1] : 0.0};
+#if EQLB_STRESS_REPCR
+    {
+      bool pd2 = true;
+      PcrMult<P> m2;
+      pcr_chain<P, 2>(Dp_keep, am_keep, cu, sub, pd2, m2);
+    }
+#else
     pcr_apply<P, 2>(cu, mult);
+#endif
 #pragma unroll
     for (int k = 0; k < 2; ++k)
     {
@@ -770,11 +785,16 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
       const double up = from_next<P, FULL>(xs, gbase, sub, upl);
       if (owned)
       {
-        double* o = orow + k * row_stride;
-        o[pm * K + 0] += pf_m * (-zd);
-        o[pm * K + 1] += pf_m * (rev_m ? -(zd - xs) : -xs);
-        o[pp * K + 0] += pf_p * zd;
-        o[pp * K + 1] += pf_p * up;
+        // (slot address and orientation signs rebuilt from the descriptor: fewer values live across the
+        // Schur solve)
+        const double sg2 = neg_det ? -1.0 : 1.0;
+        const double pfm2 = (fm == 1) ? sg2 : -sg2, pfp2 = (fp == 1) ? sg2 : -sg2;
+        double* o = tile_slots + (((int64_t)k * tc + (int64_t)(loc - 1)) * 3 + ln) * SNPK;
+        const int pm2 = fm - ((fm > ln) ? 1 : 0), pp2 = fp - ((fp > ln) ? 1 : 0);
+        o[pm2 * K + 0] += pfm2 * (-zd);
+        o[pm2 * K + 1] += pfm2 * (rev_m ? -(zd - xs) : -xs);
+        o[pp2 * K + 0] += pfp2 * zd;
+        o[pp2 * K + 1] += pfp2 * up;
       }
     }
   }
