@@ -244,16 +244,27 @@ def test_stress_boundary_layouts(oracle_mod, k, id_bc, n):
     except RuntimeError as e:
         assert "overlapping groups" in str(e) or "To many patches" in str(e)
         pytest.skip("order-dependent grouped patches: " + str(e))
-    x = eq.equilibrate_host(G, f)
+    import stress_rank
+    bad = [nd for nd, _, _ in stress_rank.deficient_nodes(mesh, k, ft)]
+    try:
+        x = eq.equilibrate_host(G, f)
+    except RuntimeError as e:
+        # the device solve reports a singular symmetry system instead of returning numbers
+        assert "not positive definite" in str(e) and bad
+        return
     ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f, stress=True)
-    plain = oracle_mod.se_reconstruct(mesh, k, ft, G, f)
     # Patches whose two rows have different boundary types can have a rank-deficient symmetry system
-    # (checked with the independent minimiser of tests/test_oracle_stress.py: e.g. layout 1, the node between
-    # a flux-BC and a Dirichlet row); a Galerkin stress makes it consistent, the synthetic rows here (force
-    # balance only) do not, and a pivoted LU (oracle, reference) and the device solve then return different
-    # large numbers.  Where the oracle's correction stays bounded the two must agree.
-    if np.abs(ref).max() <= 5.0 * np.abs(plain).max():
-        assert np.abs(x - ref).max() <= 1e-9 * np.abs(ref).max()
+    # (tests/stress_rank.py, independent of the oracle: e.g. the node between a flux-BC and a Dirichlet row on a
+    # straight side, or the right-angled two-cell corner at RT_2).  A Galerkin stress makes it consistent, the
+    # synthetic rows here (force balance only) do not, and a pivoted LU (oracle, reference) and the device solve
+    # then return different members.  Corrections are patch-local, so every cell outside those patches must
+    # agree to rounding.
+    keep = np.ones(mesh.ncells, dtype=bool)
+    for nd in bad:
+        keep[mesh.node_cells[mesh.node_cells_offsets[nd]:mesh.node_cells_offsets[nd + 1]]] = False
+    assert keep.sum() >= mesh.ncells // 4
+    xc, rc = x.reshape(2, mesh.ncells, -1)[:, keep], ref.reshape(2, mesh.ncells, -1)[:, keep]
+    assert np.abs(xc - rc).max() <= 1e-9 * np.abs(rc).max()
     # row-wise conditions hold whatever the symmetry step does: divergence, jumps, flux BCs
     from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
     for r in range(2):
