@@ -38,6 +38,30 @@ EXPORTED_SYMBOLS = [
 _lib = None
 
 
+def _bind_torch_hip_runtime():
+    """torch bundles its own HIP runtime (torch/lib/libamdhip64.so, same soname as /opt/rocm's).  Two
+    runtimes in one process do not share devices: the one initialised second sees none.  Callers that
+    hand torch tensors to this library (bench.py, distributed.HaloExchange) therefore need ONE runtime,
+    torch's.  If torch is installed but not imported yet, its runtime is mapped first (without importing
+    torch), so that libeqlb_amd.so binds to it and a later `import torch` finds it already loaded."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # a torch build without a usable bundled runtime: the system runtime is used
+
+
 def lib():
     """Load libeqlb_amd.so; raises if it has not been built (no fallback)."""
     global _lib
@@ -46,6 +70,7 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} not found: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()')")
+        _bind_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.eqlb_last_error.restype = C.c_char_p
         L.eqlb_device_count.restype = C.c_int
