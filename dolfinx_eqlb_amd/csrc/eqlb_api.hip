@@ -1761,6 +1761,13 @@ int eqlb_ev_set_option(eqlb_ev_t* h, const char* key, int32_t value)
     dfree(h->se->d_rhs_dg);
     return EQLB_OK;
   }
+  if (!strcmp(key, "boundary_basis"))
+  {
+    if (value != 0 && value != 1)
+      return fail(EQLB_ERR_INVALID_ARGUMENT, "unknown boundary basis %d", value);
+    h->se->ev_bv_hier = value;
+    return EQLB_OK;
+  }
   if (!strcmp(key, "timing") || !strcmp(key, "scatter") || !strcmp(key, "accumulate"))
     return eqlb_se_set_option(h->se, key, value);
   return fail(EQLB_ERR_INVALID_ARGUMENT, "unknown option '%s'", key);
@@ -1909,7 +1916,7 @@ int eqlb_ev_set_boundary(eqlb_ev_t* h, const int8_t* facet_type, const double* b
     if (e == hipSuccess)
     {
       eqlb::launch_ev_boundary_to_broken(m, se->k, se->nrhs, se->ev_cell_dofs, se->ev_ndofs, d_conf, se->bvals,
-                                         se->ev_basis ? se->ev_basis + se->nrt * se->nrt + se->k * se->k : nullptr, nullptr);
+                                         (se->ev_basis && !se->ev_bv_hier) ? se->ev_basis + se->nrt * se->nrt + se->k * se->k : nullptr, nullptr);
       e = hipDeviceSynchronize();
     }
     dfree(d_conf);

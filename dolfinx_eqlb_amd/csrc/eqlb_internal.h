@@ -223,6 +223,7 @@ struct eqlb_se
   int scatter_last = EQLB_SCATTER_SLOTS; // scatter mode the last equilibrate call resolved to
   int mode = 0;                     // 1: constrained-minimisation (EV) patch problems
   int ev_output = 0;                // EV: 0 conforming DOFs, 1 broken hierarchic RT_k layout
+  int ev_bv_hier = 0;               // EV: boundary values in the hierarchic basis although a basis transform is set
   int32_t* ev_cell_dofs = nullptr;  // EV: device copy of the caller's dofmap or nullptr (default)
   int64_t ev_ndofs = 0;             // EV: number of conforming flux DOFs
   double* ev_basis = nullptr;       // EV: device copy of [C (nrt x nrt) | R (k x k) | facet maps 3 x 2 x k x k] or nullptr

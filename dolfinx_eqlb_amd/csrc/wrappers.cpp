@@ -310,6 +310,7 @@ struct BoundaryData
   // known only then, se/reconstruction.hpp:363-373) and kept
   eqlb_se_t* se = nullptr;
   eqlb_ev_t* ev = nullptr;
+  std::vector<double> basis_C, basis_R;
   int se_degree_dg = -1;
 
   BoundaryData(std::vector<std::vector<std::shared_ptr<FluxBC>>>& list_bcs,
@@ -460,9 +461,37 @@ struct BoundaryData
     check(eqlb_ev_create(mesh->h, k, nrhs, &ev));
     if (!V->cell_dofs.empty())
       check(eqlb_ev_set_dofmap(ev, V->cell_dofs.data(), V->ndofs_user));
+    if (!basis_C.empty())
+    {
+      // the boundary DOFs of this object are facet moments, i.e. hierarchic DOFs: the library converts them
+      check(eqlb_ev_set_basis_transform(ev, basis_C.data(), basis_R.empty() ? nullptr : basis_R.data()));
+      check(eqlb_ev_set_option(ev, "boundary_basis", 1));
+    }
     check(eqlb_ev_set_boundary(ev, facet_type.data(), boundary_values.empty() ? nullptr : boundary_values.data(),
                                nullptr));
     return ev;
+  }
+  // Output basis of the conforming flux (eqlb_ev_set_basis_transform): C [k(k+2)]^2 from the hierarchic
+  // reference coefficients to the target element's, R [k]^2 for the facet block of reflected facets.
+  void set_basis_transform(const py::array_t<double, py::array::c_style | py::array::forcecast>& C,
+                           const py::object& R)
+  {
+    if (custom)
+      throw std::runtime_error("set_basis_transform: only for the conforming (minimisation) flux space");
+    const int nrt = k * (k + 2);
+    if (C.ndim() != 2 || C.shape(0) != nrt || C.shape(1) != nrt)
+      throw std::runtime_error("set_basis_transform: C must be [k(k+2), k(k+2)]");
+    basis_C.assign(C.data(), C.data() + (size_t)nrt * nrt);
+    basis_R.clear();
+    if (!R.is_none())
+    {
+      auto r = R.cast<py::array_t<double, py::array::c_style | py::array::forcecast>>();
+      if (r.ndim() != 2 || r.shape(0) != k || r.shape(1) != k)
+        throw std::runtime_error("set_basis_transform: R must be [k, k]");
+      basis_R.assign(r.data(), r.data() + (size_t)k * k);
+    }
+    eqlb_ev_destroy(ev); // rebuilt with the new basis on the next call
+    ev = nullptr;
   }
   void set_option(const std::string& key, int value)
   {
@@ -695,6 +724,8 @@ PYBIND11_MODULE(_cpp, m)
            py::arg("list_of_bcs"), py::arg("list_of_boundary_fluxes"), py::arg("V_flux_hdiv"),
            py::arg("rtflux_is_custom"), py::arg("quadrature_degree"), py::arg("list_bfcts_prime"),
            py::arg("reconstruct_stress"))
+      .def("set_basis_transform", &BoundaryData::set_basis_transform, py::arg("C"), py::arg("R") = py::none(),
+           "Output basis of the conforming flux: y_cell = C c_cell, R on the facet block of reflected facets")
       .def("set_option", &BoundaryData::set_option, py::arg("key"), py::arg("value"),
            "Integer options of the device handle (eqlb_se_set_option / eqlb_ev_set_option)")
       .def_property_readonly("facet_type", [](const BoundaryData& b) {

@@ -314,7 +314,10 @@ void eqlb_ev_destroy(eqlb_ev_t* handle);
 
 /* "output": 0 conforming DOFs (default), 1 broken hierarchic RT_k layout [ncells*k(k+2)] as
  * eqlb_se_equilibrate writes it; "timing", "scatter" (EQLB_SCATTER_AUTO / _SLOTS / _TILED),
- * "accumulate": as eqlb_se_set_option. */
+ * "accumulate": as eqlb_se_set_option; "boundary_basis": 0 (default) the boundary values of
+ * eqlb_ev_set_boundary are DOFs of the output basis (eqlb_ev_set_basis_transform), 1 they are DOFs of the
+ * conforming hierarchic RT_k whatever the output basis (what a caller has who computes the facet moments
+ * int_E g s^j itself; set before eqlb_ev_set_boundary). */
 int eqlb_ev_set_option(eqlb_ev_t* handle, const char* key, int32_t value);
 
 /* cell_dofs [ncells][k(k+2)] host array (NULL restores the default numbering), ndofs = size of the

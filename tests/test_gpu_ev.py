@@ -273,3 +273,9 @@ def test_ev_basis_transform_with_boundary_values(oracle_mod, k):
     got = eq.equilibrate_host(G[None], f[None])[0]
     ref = _transform_reference(mesh, k, xb, C, R, cd, nd)
     assert np.abs(got - ref).max() <= 1e-11 * np.abs(ref).max()
+    # option "boundary_basis" = 1: the boundary values stay hierarchic facet moments, only the output changes
+    eq_h = cpp.ConstrainedMinEquilibrator(dm, k, 1)
+    eq_h.set_basis_transform(C, R)
+    eq_h.set_option("boundary_basis", 1)
+    eq_h.set_boundary(ft, boundary_values=broken_to_conforming(mesh, k, bv)[None])
+    assert np.abs(eq_h.equilibrate_host(G[None], f[None])[0] - ref).max() <= 1e-11 * np.abs(ref).max()

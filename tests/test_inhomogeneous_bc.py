@@ -120,3 +120,50 @@ def test_class_api_with_inhomogeneous_fluxbc(oracle_mod, k):
     with pytest.raises(RuntimeError, match="does not match"):
         from dolfinx_eqlb_amd.eqlb import boundarydata
         boundarydata([[]], [], (mesh, k), True, [prime], False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [2, 3])
+def test_class_api_ev_in_another_basis(oracle_mod, k):
+    """FluxEqlbEV with BoundaryData.set_basis_transform (the hook for Basix' RT_k): the
+    boundary DOFs the BoundaryData computes from the FluxBC stay facet moments (option "boundary_basis" = 1
+    inside the module), the output arrives in the target basis.  Reference: C / R applied in numpy to the
+    broken hierarchic result."""
+    from test_gpu_ev import _transform_reference
+    from dolfinx_eqlb_amd import cpp
+    from dolfinx_eqlb_amd.eqlb import FluxEqlbEV, fluxbc
+    from dolfinx_eqlb_amd.eqlb.conforming import broken_to_conforming, conforming_dofmap, reversal_matrix
+    mesh, ft, G, f, bv, w = case(6, k, "neumann_lt")
+    nrt = k * (k + 2)
+    bf = mesh.boundary_facets()
+    prime, dual = bf[ft[0][bf] == 1], bf[ft[0][bf] == 2]
+    cd, nd = conforming_dofmap(mesh, k)
+    ev = FluxEqlbEV(k, mesh, [f], [G])
+    ev.set_boundary_conditions([prime], [[fluxbc(w, dual)]])
+    ev.equilibrate_fluxes()
+    x_hier = np.array(ev.get_reconstructed_fluxes(0), copy=True)
+    base = cpp.ConstrainedMinEquilibrator(cpp.DeviceMesh(mesh), k, 1)
+    base.set_option("output", 1)
+    base.set_boundary(ft, boundary_values=broken_to_conforming(mesh, k, bv)[None])
+    xb = base.equilibrate_host(G[None], f[None])[0]
+    rng = np.random.default_rng(3)
+    C = rng.standard_normal((nrt, nrt))
+    for fl in range(3):
+        C[fl * k:(fl + 1) * k, :] = 0.0
+        C[fl * k:(fl + 1) * k, fl * k:(fl + 1) * k] = rng.standard_normal((k, k)) + 2.0 * np.eye(k)
+    R = rng.standard_normal((k, k)) + 2.0 * np.eye(k)
+    ev2 = FluxEqlbEV(k, mesh, [f], [G])
+    ev2.set_boundary_conditions([prime], [[fluxbc(w, dual)]])
+    ev2.boundary_data.set_basis_transform(C, R)
+    ev2.equilibrate_fluxes()
+    ref = _transform_reference(mesh, k, xb, C, R, cd, nd)
+    assert np.abs(ev2.get_reconstructed_fluxes(0) - ref).max() <= 1e-11 * np.abs(ref).max()
+    # the hierarchic basis written as a transform
+    Ci = np.diag(np.concatenate([-np.ones(3 * k), np.ones(nrt - 3 * k)]))
+    ev3 = FluxEqlbEV(k, mesh, [f], [G])
+    ev3.set_boundary_conditions([prime], [[fluxbc(w, dual)]])
+    ev3.boundary_data.set_basis_transform(Ci, -reversal_matrix(k))
+    ev3.equilibrate_fluxes()
+    assert np.abs(ev3.get_reconstructed_fluxes(0) - x_hier).max() <= 1e-12 * np.abs(x_hier).max()
+    with pytest.raises(RuntimeError, match="k\\(k\\+2\\)"):
+        ev3.boundary_data.set_basis_transform(np.eye(3), None)
