@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "eqlb_se_check_status", "eqlb_ev_check_status",
     "eqlb_se_set_priority_cells", "eqlb_se_num_priority_tiles", "eqlb_se_equilibrate_tiles",
     "eqlb_se_equilibrate_lists", "eqlb_ev_equilibrate_lists", "eqlb_se_kornconst",
-    "eqlb_ev_set_basis_transform",
+    "eqlb_ev_set_basis_transform", "eqlb_se_estimate_stress", "eqlb_oscillation",
 ]
 
 _lib = None
@@ -409,6 +409,45 @@ def estimate(dmesh: DeviceMesh, k: int, flux_hdiv, flux_dg, rhs_dg, conforming_f
     _check(fn(dmesh._h, C.c_int32(k), C.c_int32(nrhs), _hp(x), _hp(g), _hp(f),
               _hp(div2), _hp(sig2), _hp(jump), C.c_int32(MEM_HOST), None))
     return div2, sig2, jump
+
+
+def estimate_stress(dmesh: DeviceMesh, k: int, flux_hdiv, korn=None, pi_1: float = 1.0):
+    """eqlb_se_estimate_stress on host arrays: flux_hdiv [2, ncells*k(k+2)] (rows of the equilibrated
+    stress), korn [ncells] cell-wise Korn constants or None.  Returns (cell_energy [ncells],
+    cell_wsym [ncells], node_asym [nnodes])."""
+    m = dmesh.mesh
+    x = np.ascontiguousarray(flux_hdiv, dtype=np.float64)
+    if x.size != 2 * m.ncells * k * (k + 2):
+        raise RuntimeError("Equilibration: Input sizes does not match")
+    kc = None if korn is None else np.ascontiguousarray(korn, dtype=np.float64)
+    if kc is not None and kc.size != m.ncells:
+        raise RuntimeError("Equilibration: Input sizes does not match")
+    energy, wsym, asym = np.zeros(m.ncells), np.zeros(m.ncells), np.zeros(m.nnodes)
+    _check(lib().eqlb_se_estimate_stress(dmesh._h, C.c_int32(k), _hp(x), _hp(kc) if kc is not None else None,
+                                         C.c_double(pi_1), _hp(energy), _hp(wsym), _hp(asym),
+                                         C.c_int32(MEM_HOST), None))
+    return energy, wsym, asym
+
+
+def oscillation(dmesh: DeviceMesh, k: int, flux, flux_dg, qpoints, qweights, fvalues, korn=None):
+    """eqlb_oscillation on host arrays: flux [nrhs, ncells*k(k+2)], flux_dg [nrhs, ncells*k(k+1)] or None
+    (conforming flux in the broken layout), fvalues [nrhs, ncells, nq].  Returns [nrhs, ncells]."""
+    m = dmesh.mesh
+    x = np.ascontiguousarray(flux, dtype=np.float64).reshape(-1, m.ncells * k * (k + 2))
+    nrhs = x.shape[0]
+    g = None if flux_dg is None else np.ascontiguousarray(flux_dg, dtype=np.float64).reshape(nrhs, -1)
+    qp = np.ascontiguousarray(qpoints, dtype=np.float64)
+    qw = np.ascontiguousarray(qweights, dtype=np.float64)
+    nq = qw.size
+    fv = np.ascontiguousarray(fvalues, dtype=np.float64)
+    if fv.size != nrhs * m.ncells * nq or (g is not None and g.shape[1] != m.ncells * k * (k + 1)):
+        raise RuntimeError("Equilibration: Input sizes does not match")
+    kc = None if korn is None else np.ascontiguousarray(korn, dtype=np.float64)
+    out = np.zeros((nrhs, m.ncells))
+    _check(lib().eqlb_oscillation(dmesh._h, C.c_int32(k), C.c_int32(nrhs), _hp(x),
+                                  _hp(g) if g is not None else None, C.c_int32(nq), _hp(qp), _hp(qw), _hp(fv),
+                                  _hp(kc) if kc is not None else None, _hp(out), C.c_int32(MEM_HOST), None))
+    return out
 
 
 def halo_pack(x_ptr, cells_ptr, buf_ptr, nrhs, nlist, nrt, ncells, clear=True, stream=0):

@@ -687,6 +687,7 @@ void eqlb_mesh_destroy(eqlb_mesh_t* m)
   dfree(d.node_cells_off);
   dfree(d.node_facets_off);
   dfree(d.node_facets);
+  dfree(d.node_cells);
   dfree(d.facet_perm);
   delete m;
 }
@@ -1696,6 +1697,122 @@ int eqlb_ev_estimate(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const double* f
 {
   return estimate_impl(mesh, k, nrhs, flux_broken, flux_dg, rhs_dg, cell_div2, cell_sig2, facet_jump,
                        memspace, stream, -1.0, 0.0);
+}
+
+// Host arrays of a call staged on the device for its duration (inputs copied in, outputs copied back).
+namespace
+{
+struct Staging
+{
+  std::vector<double*> bufs;
+  struct Out
+  {
+    double *host, *dev;
+    size_t n;
+  };
+  std::vector<Out> outs;
+  bool bad = false;
+  const double* in(const double* host, size_t n)
+  {
+    if (!host)
+      return nullptr;
+    double* d = nullptr;
+    if (upload(&d, host, n))
+      bad = true;
+    bufs.push_back(d);
+    return d;
+  }
+  double* out(double* host, size_t n)
+  {
+    if (!host)
+      return nullptr;
+    double* d = nullptr;
+    if (upload<double>(&d, nullptr, n))
+      bad = true;
+    bufs.push_back(d);
+    outs.push_back({host, d, n});
+    return d;
+  }
+  bool fetch()
+  {
+    for (const Out& o : outs)
+      if (hipMemcpy(o.host, o.dev, o.n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        return false;
+    return true;
+  }
+  ~Staging()
+  {
+    for (double* b : bufs)
+      if (b)
+        (void)hipFree(b);
+  }
+};
+} // namespace
+
+int eqlb_se_estimate_stress(eqlb_mesh_t* mesh, int32_t k, const double* flux_hdiv, const double* korn,
+                            double pi_1, double* cell_energy, double* cell_wsym, double* node_asym,
+                            int32_t memspace, void* stream_)
+{
+  if (!mesh || !flux_hdiv || k < 1 || k > 3 || !(pi_1 > -1.0))
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_estimate_stress: invalid argument");
+  if (memspace != EQLB_MEM_DEVICE && memspace != EQLB_MEM_HOST)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_estimate_stress: unknown memory space");
+  eqlb::DeviceMesh& m = mesh->m;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (node_asym && !m.node_cells && upload(&m.node_cells, m.h_node_cells.data(), m.h_node_cells.size()))
+    return fail(EQLB_ERR_DEVICE, "eqlb_se_estimate_stress: device allocation failed");
+  const size_t nx = (size_t)m.ncells * k * (k + 2);
+  int rc;
+  if (memspace == EQLB_MEM_DEVICE)
+    rc = eqlb::launch_estimate_stress(m, m.node_cells, k, flux_hdiv, flux_hdiv + nx, korn, pi_1, cell_energy,
+                                      cell_wsym, node_asym, stream);
+  else
+  {
+    Staging s;
+    const double* d_x = s.in(flux_hdiv, 2 * nx);
+    const double* d_k = s.in(korn, m.ncells);
+    double* d_e = s.out(cell_energy, m.ncells);
+    double* d_w = s.out(cell_wsym, m.ncells);
+    double* d_a = s.out(node_asym, m.nnodes);
+    if (s.bad)
+      return fail(EQLB_ERR_DEVICE, "eqlb_se_estimate_stress: device allocation failed");
+    rc = eqlb::launch_estimate_stress(m, m.node_cells, k, d_x, d_x + nx, d_k, pi_1, d_e, d_w, d_a, stream);
+    if (!rc && !s.fetch())
+      rc = EQLB_ERR_DEVICE;
+  }
+  return rc ? fail(rc, "eqlb_se_estimate_stress: device error") : EQLB_OK;
+}
+
+int eqlb_oscillation(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const double* flux, const double* flux_dg,
+                     int32_t nq, const double* qpoints, const double* qweights, const double* fvalues,
+                     const double* korn, double* out, int32_t memspace, void* stream_)
+{
+  if (!mesh || !flux || !qpoints || !qweights || !fvalues || !out || nrhs < 1 || k < 1 || k > 3 || nq < 1
+      || nq > 128)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_oscillation: invalid argument");
+  if (memspace != EQLB_MEM_DEVICE && memspace != EQLB_MEM_HOST)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_oscillation: unknown memory space");
+  const eqlb::DeviceMesh& m = mesh->m;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const size_t nx = (size_t)nrhs * m.ncells * k * (k + 2), ng = (size_t)nrhs * m.ncells * k * (k + 1);
+  int rc;
+  if (memspace == EQLB_MEM_DEVICE)
+    rc = eqlb::launch_oscillation(m, k, nrhs, flux, flux_dg, nq, qpoints, qweights, fvalues, korn, out, stream);
+  else
+  {
+    Staging s;
+    const double* d_x = s.in(flux, nx);
+    const double* d_g = s.in(flux_dg, ng);
+    const double* d_f = s.in(fvalues, (size_t)nrhs * m.ncells * nq);
+    const double* d_k = s.in(korn, m.ncells);
+    double* d_o = s.out(out, (size_t)nrhs * m.ncells);
+    if (s.bad)
+      return fail(EQLB_ERR_DEVICE, "eqlb_oscillation: device allocation failed");
+    rc = eqlb::launch_oscillation(m, k, nrhs, d_x, d_g, nq, qpoints, qweights, d_f, d_k, d_o, stream);
+    if (!rc && !s.fetch())
+      rc = EQLB_ERR_DEVICE;
+  }
+  return rc ? fail(rc, "eqlb_oscillation: device error") : EQLB_OK;
 }
 
 int eqlb_halo_pack(int32_t nrhs, int32_t nlist, int32_t nrt, int64_t ncells, const int64_t* cells,

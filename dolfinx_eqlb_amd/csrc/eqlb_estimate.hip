@@ -9,6 +9,8 @@
 // and the normal-flux jump of sigma_eq + G on an interior facet from the outward moments of both
 // cells (reversal matrix B when their facet parameters run against each other).
 #include "eqlb_device_common.h"
+#include <cmath>
+#include <vector>
 #include "eqlb_tables_gen.h"
 
 namespace eqlb
@@ -261,5 +263,295 @@ int launch_estimate(const DeviceMesh& m, int k, int nrhs, const double* x_eq, co
     return launch_estimate_k<3>(m, nrhs, x_eq, flux_dg, rhs_dg, div2, sig2, jump, alpha, beta, stream);
   return EQLB_ERR_UNSUPPORTED;
 }
+
+// ---- stress estimator (demo/elasticity/demo_error_estimation.py:49-148) --------------------------------
+// delta_sigma = (row 0; row 1) of an equilibrated stress.  Per cell, with W^{ab}_{rs} = c_r^T SU^{ab} c_s on the
+// reference cell and int_T sigma_r^x sigma_s^y = (1/|detJ|) sum_ab J_xa J_yb W^{ab}_{rs}:
+//   energy = int delta_sigma : A delta_sigma,  A tau = (tau - pi_1/(2 + 2 pi_1) tr(tau) I) / 2        (:100-102,109)
+//   wsym   = int (C_K (dsig_01 - dsig_10) / 2)^2                                                         (:108,121)
+//   asym3  = int (dsig_01 - dsig_10) hat_v  per vertex (the weak symmetry condition,
+//            python/dolfinx_eqlb/eqlb/check_eqlb_conditions.py:476-521, before assembly over the nodes)
+template <int K>
+__global__ void __launch_bounds__(256)
+k_estimate_stress_cells(int32_t ncells, const double* __restrict__ tab, const double* __restrict__ cellJ,
+                        const double* __restrict__ x0, const double* __restrict__ x1,
+                        const double* __restrict__ korn, const double pi_1, double* __restrict__ energy,
+                        double* __restrict__ wsym, double* __restrict__ asym3)
+{
+  using R = eqlb_tables::Ref<K, K - 1>;
+  constexpr int NRT = R::NRT, NSU = R::SU_SIZE, NV = R::V_SIZE;
+  extern __shared__ double st[];
+  for (int i = threadIdx.x; i < NSU + NV; i += 256)
+    st[i] = tab[i];
+  __syncthreads();
+  const int32_t c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncells)
+    return;
+  const double* J = cellJ + 4 * (int64_t)c;
+  const double Jm[2][2] = {{J[0], J[1]}, {J[2], J[3]}};
+  const double detJ = J[0] * J[3] - J[1] * J[2], ia = 1.0 / fabs(detJ);
+  double c0[NRT], c1[NRT];
+#pragma unroll
+  for (int i = 0; i < NRT; ++i)
+  {
+    c0[i] = x0[(int64_t)c * NRT + i];
+    c1[i] = x1[(int64_t)c * NRT + i];
+  }
+  // W[t][r][s] = c_r^T SU_t c_s, t = (xx, xy, yy)
+  double W[3][2][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+  {
+    double w00 = 0.0, w01 = 0.0, w10 = 0.0, w11 = 0.0;
+    for (int i = 0; i < NRT; ++i)
+    {
+      double u0 = 0.0, u1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < NRT; ++j)
+      {
+        const double a = st[(t * NRT + i) * NRT + j];
+        u0 += a * c0[j];
+        u1 += a * c1[j];
+      }
+      w00 += c0[i] * u0;
+      w01 += c0[i] * u1;
+      w10 += c1[i] * u0;
+      w11 += c1[i] * u1;
+    }
+    W[t][0][0] = w00;
+    W[t][0][1] = w01;
+    W[t][1][0] = w10;
+    W[t][1][1] = w11;
+  }
+  // int_T sigma_r^x sigma_s^y
+  auto prod = [&](int x, int y, int r, int s) {
+    return ia
+           * (Jm[x][0] * Jm[y][0] * W[0][r][s] + Jm[x][0] * Jm[y][1] * W[1][r][s] + Jm[x][1] * Jm[y][0] * W[1][s][r]
+              + Jm[x][1] * Jm[y][1] * W[2][r][s]);
+  };
+  const double fro = prod(0, 0, 0, 0) + prod(1, 1, 0, 0) + prod(0, 0, 1, 1) + prod(1, 1, 1, 1);
+  const double tr2 = prod(0, 0, 0, 0) + 2.0 * prod(0, 1, 0, 1) + prod(1, 1, 1, 1);
+  const double as2 = prod(1, 1, 0, 0) - 2.0 * prod(1, 0, 0, 1) + prod(0, 0, 1, 1);
+  const double ck = korn ? korn[c] : 1.0;
+  if (energy)
+    energy[c] = 0.5 * (fro - pi_1 / (2.0 + 2.0 * pi_1) * tr2);
+  if (wsym)
+    wsym[c] = 0.25 * ck * ck * as2;
+  if (asym3)
+  {
+    const double sg = (detJ > 0.0) ? 1.0 : -1.0;
+    const double* V = st + NSU; // V[v][i][a] = int hat_v phi_i^a
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+    {
+      double r = 0.0;
+      for (int i = 0; i < NRT; ++i)
+      {
+        const double v0 = V[(v * NRT + i) * 2], v1 = V[(v * NRT + i) * 2 + 1];
+        r += c0[i] * (Jm[1][0] * v0 + Jm[1][1] * v1) - c1[i] * (Jm[0][0] * v0 + Jm[0][1] * v1);
+      }
+      asym3[(int64_t)c * 3 + v] = sg * r;
+    }
+  }
+}
+
+// node value = sum of the vertex values of the cells around the node, in the order of the CSR list
+__global__ void __launch_bounds__(256)
+k_gather_vertex_values(int32_t nnodes, const int32_t* __restrict__ node_cells_off,
+                       const int32_t* __restrict__ node_cells, const int32_t* __restrict__ cell_nodes,
+                       const double* __restrict__ val3, double* __restrict__ out)
+{
+  const int32_t n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= nnodes)
+    return;
+  double s = 0.0;
+  for (int32_t o = node_cells_off[n]; o < node_cells_off[n + 1]; ++o)
+  {
+    const int32_t c = node_cells[o];
+    const int v = (cell_nodes[(int64_t)c * 3 + 1] == n) ? 1 : ((cell_nodes[(int64_t)c * 3 + 2] == n) ? 2 : 0);
+    s += val3[(int64_t)c * 3 + v];
+  }
+  out[n] = s;
+}
+
+template <int K>
+static int launch_estimate_stress_k(const DeviceMesh& m, const int32_t* node_cells, const double* x0,
+                                    const double* x1, const double* korn, double pi_1, double* energy,
+                                    double* wsym, double* node_asym, hipStream_t stream)
+{
+  using R = eqlb_tables::Ref<K, K - 1>;
+  std::vector<double> t(R::SU, R::SU + R::SU_SIZE);
+  t.insert(t.end(), R::V, R::V + R::V_SIZE);
+  double *d_t = nullptr, *d_a = nullptr;
+  if (hipMalloc(&d_t, t.size() * sizeof(double)) != hipSuccess)
+    return EQLB_ERR_DEVICE;
+  if (node_asym && hipMalloc(&d_a, sizeof(double) * 3 * (size_t)m.ncells) != hipSuccess)
+  {
+    (void)hipFree(d_t);
+    return EQLB_ERR_DEVICE;
+  }
+  hipError_t e = hipMemcpyAsync(d_t, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess)
+  {
+    hipLaunchKernelGGL(k_estimate_stress_cells<K>, dim3((m.ncells + 255) / 256), dim3(256),
+                       t.size() * sizeof(double), stream, m.ncells, d_t, m.cellJ, x0, x1, korn, pi_1, energy, wsym,
+                       d_a);
+    if (node_asym)
+      hipLaunchKernelGGL(k_gather_vertex_values, dim3((m.nnodes + 255) / 256), dim3(256), 0, stream, m.nnodes,
+                         m.node_cells_off, node_cells, m.cell_nodes, d_a, node_asym);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(stream); // the buffers are freed below
+  (void)hipFree(d_t);
+  (void)hipFree(d_a);
+  return (e == hipSuccess) ? 0 : EQLB_ERR_DEVICE;
+}
+
+int launch_estimate_stress(const DeviceMesh& m, const int32_t* node_cells, int k, const double* x0,
+                           const double* x1, const double* korn, double pi_1, double* energy, double* wsym,
+                           double* node_asym, hipStream_t stream)
+{
+  if (k == 1)
+    return launch_estimate_stress_k<1>(m, node_cells, x0, x1, korn, pi_1, energy, wsym, node_asym, stream);
+  if (k == 2)
+    return launch_estimate_stress_k<2>(m, node_cells, x0, x1, korn, pi_1, energy, wsym, node_asym, stream);
+  if (k == 3)
+    return launch_estimate_stress_k<3>(m, node_cells, x0, x1, korn, pi_1, energy, wsym, node_asym, stream);
+  return EQLB_ERR_UNSUPPORTED;
+}
+
+// ---- data oscillation ((h_T / pi) || f - div sigma ||_T of demo/poisson/demo_error_estimation.py:93-100,
+//      with the Korn constant in front for stresses, demo/elasticity/demo_error_estimation.py:104-106) -------
+// detJ * div(sigma_eq + beta G) is a polynomial of P_{k-1}(ref): its monomial coefficients are GMI * (moments),
+// the moments as in k_estimate_cells.  f comes as point values at the images of a reference rule.
+// qtab: [nq][NQ] monomial values at the points, then [nq] weights.
+template <int K>
+__global__ void __launch_bounds__(256)
+k_oscillation_cells(int32_t ncells, const double* __restrict__ tab, const double* __restrict__ qtab, int nq,
+                    const double* __restrict__ cellJ, const double* __restrict__ x_eq,
+                    const double* __restrict__ flux_dg, const double* __restrict__ fvalues,
+                    const double* __restrict__ korn, double* __restrict__ out)
+{
+  using E = EstTables<K>;
+  constexpr int NRT = E::NRT, ND = E::ND, NQ = E::NQ;
+  extern __shared__ double st[];
+  double* sq = st + E::TOTAL;
+  for (int i = threadIdx.x; i < E::TOTAL; i += 256)
+    st[i] = tab[i];
+  for (int i = threadIdx.x; i < nq * (NQ + 1); i += 256)
+    sq[i] = qtab[i];
+  __syncthreads();
+  const int32_t c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncells)
+    return;
+  const double* J = cellJ + 4 * (int64_t)c;
+  const double J00 = J[0], J01 = J[1], J10 = J[2], J11 = J[3];
+  const double detJ = J00 * J11 - J01 * J10;
+  const double a00 = J11, a01 = -J01, a10 = -J10, a11 = J00;
+  const double* cf = x_eq + (int64_t)c * NRT;
+  double m[NQ];
+  m[0] = -cf[0] + cf[K] - cf[2 * K];
+#pragma unroll
+  for (int q = 1; q < NQ; ++q)
+    m[q] = cf[3 * K + q - 1];
+  if (flux_dg)
+  {
+    const double* G = flux_dg + (int64_t)c * ND * 2;
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+    {
+      const double gx = G[2 * i], gy = G[2 * i + 1];
+      const double h0 = a00 * gx + a01 * gy, h1 = a10 * gx + a11 * gy;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        m[q] += h0 * st[E::OFF_DM + (i * 2 + 0) * NQ + q] + h1 * st[E::OFF_DM + (i * 2 + 1) * NQ + q];
+    }
+  }
+  double a[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    double r = 0.0;
+#pragma unroll
+    for (int p = 0; p < NQ; ++p)
+      r += st[E::OFF_GMI + q * NQ + p] * m[p];
+    a[q] = r / detJ;
+  }
+  const double* fv = fvalues + (int64_t)c * nq;
+  double s = 0.0;
+  for (int q = 0; q < nq; ++q)
+  {
+    double d = fv[q];
+#pragma unroll
+    for (int p = 0; p < NQ; ++p)
+      d -= a[p] * sq[q * NQ + p];
+    s += sq[nq * NQ + q] * d * d;
+  }
+  // cell diameter as dolfinx::mesh::h: the longest edge of the triangle
+  const double e1 = J00 * J00 + J10 * J10, e2 = J01 * J01 + J11 * J11,
+               e3 = (J01 - J00) * (J01 - J00) + (J11 - J10) * (J11 - J10);
+  const double h2 = fmax(e1, fmax(e2, e3));
+  const double ck = korn ? korn[c] : 1.0;
+  constexpr double PI = 3.14159265358979323846;
+  out[c] = ck * ck * h2 / (PI * PI) * fabs(detJ) * s;
+}
+
+template <int K>
+static int launch_oscillation_k(const DeviceMesh& m, int nrhs, const double* x_eq, const double* flux_dg, int nq,
+                                const double* qpoints, const double* qweights, const double* fvalues,
+                                const double* korn, double* out, hipStream_t stream)
+{
+  using E = EstTables<K>;
+  using R = eqlb_tables::Ref<K, K - 1>;
+  std::vector<double> t;
+  E::fill(t);
+  std::vector<double> qt((size_t)nq * (E::NQ + 1));
+  for (int q = 0; q < nq; ++q)
+  {
+    for (int p = 0; p < E::NQ; ++p)
+      qt[(size_t)q * E::NQ + p] = std::pow(qpoints[2 * q], R::MONO_X[p]) * std::pow(qpoints[2 * q + 1], R::MONO_Y[p]);
+    qt[(size_t)nq * E::NQ + q] = qweights[q];
+  }
+  double *d_t = nullptr, *d_q = nullptr;
+  if (hipMalloc(&d_t, t.size() * sizeof(double)) != hipSuccess)
+    return EQLB_ERR_DEVICE;
+  if (hipMalloc(&d_q, qt.size() * sizeof(double)) != hipSuccess)
+  {
+    (void)hipFree(d_t);
+    return EQLB_ERR_DEVICE;
+  }
+  hipError_t e = hipMemcpyAsync(d_t, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(d_q, qt.data(), qt.size() * sizeof(double), hipMemcpyHostToDevice, stream);
+  const size_t lds = (t.size() + qt.size()) * sizeof(double);
+  const int64_t nx = (int64_t)m.ncells * E::NRT, ng = (int64_t)m.ncells * E::ND * 2;
+  for (int r = 0; r < nrhs && e == hipSuccess; ++r)
+  {
+    hipLaunchKernelGGL(k_oscillation_cells<K>, dim3((m.ncells + 255) / 256), dim3(256), lds, stream, m.ncells, d_t,
+                       d_q, nq, m.cellJ, x_eq + r * nx, flux_dg ? flux_dg + r * ng : nullptr,
+                       fvalues + (int64_t)r * m.ncells * nq, korn, out + (int64_t)r * m.ncells);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(stream);
+  (void)hipFree(d_t);
+  (void)hipFree(d_q);
+  return (e == hipSuccess) ? 0 : EQLB_ERR_DEVICE;
+}
+
+int launch_oscillation(const DeviceMesh& m, int k, int nrhs, const double* x_eq, const double* flux_dg, int nq,
+                       const double* qpoints, const double* qweights, const double* fvalues, const double* korn,
+                       double* out, hipStream_t stream)
+{
+  if (k == 1)
+    return launch_oscillation_k<1>(m, nrhs, x_eq, flux_dg, nq, qpoints, qweights, fvalues, korn, out, stream);
+  if (k == 2)
+    return launch_oscillation_k<2>(m, nrhs, x_eq, flux_dg, nq, qpoints, qweights, fvalues, korn, out, stream);
+  if (k == 3)
+    return launch_oscillation_k<3>(m, nrhs, x_eq, flux_dg, nq, qpoints, qweights, fvalues, korn, out, stream);
+  return EQLB_ERR_UNSUPPORTED;
+}
+
 
 } // namespace eqlb

@@ -44,6 +44,7 @@ struct DeviceMesh
   int32_t *cell_nodes = nullptr, *cell_facets = nullptr, *facet_nodes = nullptr;
   int32_t *facet_cells_off = nullptr, *facet_cells = nullptr;
   int32_t *node_cells_off = nullptr, *node_facets_off = nullptr, *node_facets = nullptr;
+  int32_t* node_cells = nullptr;  // uploaded on first use (node-wise gathers of the estimator step)
   uint8_t* facet_perm = nullptr;
   // host copies needed for binning / tiling
   std::vector<int32_t> h_node_ncells, h_node_nfcts, h_cell_nodes;
@@ -194,6 +195,12 @@ void launch_korn(const DeviceMesh& m, const int64_t* node_slot, const int64_t* n
 int launch_estimate(const DeviceMesh& m, int k, int nrhs, const double* x_eq, const double* flux_dg,
                     const double* rhs_dg, double* div2, double* sig2, double* jump, double alpha,
                     double beta, hipStream_t stream);
+int launch_estimate_stress(const DeviceMesh& m, const int32_t* node_cells, int k, const double* x0,
+                           const double* x1, const double* korn, double pi_1, double* energy, double* wsym,
+                           double* node_asym, hipStream_t stream);
+int launch_oscillation(const DeviceMesh& m, int k, int nrhs, const double* x_eq, const double* flux_dg, int nq,
+                       const double* qpoints, const double* qweights, const double* fvalues, const double* korn,
+                       double* out, hipStream_t stream);
 void launch_halo_pack(int nrhs, int32_t nlist, int32_t nrt, int64_t ncells, const int64_t* cells, double* x,
                       double* buf, int clear, hipStream_t stream);
 void launch_halo_unpack_add(int nrhs, int32_t nlist, int32_t nrt, int64_t ncells, const int64_t* cells,

@@ -216,3 +216,52 @@ def weak_symmetry_residual(mesh, k, sigma):
 def check_weak_symmetry_condition(mesh, k, sigma, rtol=1e-5, atol=1e-8) -> bool:
     """np.allclose(L, 0) as the reference (check_eqlb_conditions.py:517)."""
     return bool(np.allclose(weak_symmetry_residual(mesh, k, sigma)[1], 0.0, rtol=rtol, atol=atol))
+
+
+def stress_estimator_terms(mesh, k, sigma, korn=None, pi_1=1.0):
+    """Cell-wise terms of the stress estimator (demo/elasticity/demo_error_estimation.py:100-121), numpy
+    statement with quadrature: (int dsig : A dsig, int (C_K (dsig_01 - dsig_10) / 2)^2) for the rows
+    sigma [2, ncells*k(k+2)]; A tau = (tau - pi_1 / (2 + 2 pi_1) tr(tau) I) / 2."""
+    J, detJ, K = cell_geometry(mesh)
+    rt = ert.HierarchicRT(k)
+    qp, qw = make_quadrature_triangle(2 * k)
+    phi = rt.tabulate(qp)
+    c = np.asarray(sigma).reshape(2, mesh.ncells, rt.ndofs)
+    val = np.einsum("cxa,rci,qia->rcqx", J, c, phi) / detJ[None, :, None, None]   # [row, cell, q, comp]
+    w = qw[None] * np.abs(detJ)[:, None]
+    fro = np.einsum("cq,rcqx,rcqx->c", w, val, val)
+    tr = val[0, ..., 0] + val[1, ..., 1]
+    asym = val[0, ..., 1] - val[1, ..., 0]
+    ck = np.ones(mesh.ncells) if korn is None else np.asarray(korn)
+    energy = 0.5 * (fro - pi_1 / (2.0 + 2.0 * pi_1) * np.einsum("cq,cq,cq->c", w, tr, tr))
+    wsym = 0.25 * ck ** 2 * np.einsum("cq,cq,cq->c", w, asym, asym)
+    return energy, wsym
+
+
+def cell_diameter(mesh):
+    """Longest edge per cell (dolfinx::mesh::h on triangles)."""
+    x = mesh.x[mesh.cell_nodes, :2]
+    e = np.stack([x[:, 1] - x[:, 0], x[:, 2] - x[:, 0], x[:, 2] - x[:, 1]], axis=1)
+    return np.sqrt((e ** 2).sum(axis=2)).max(axis=1)
+
+
+def oscillation_term(mesh, k, sigma, flux_dg, f, qdegree, korn=None):
+    """C_K^2 (h_T/pi)^2 || f - div(sigma + G) ||^2_T per cell (demo/poisson/demo_error_estimation.py:96-98),
+    numpy statement: f callable f(x, y), sigma [ncells*k(k+2)] broken hierarchic RT_k, flux_dg the DG_{k-1}^2
+    part G of the total flux or None."""
+    J, detJ, K = cell_geometry(mesh)
+    rt = ert.HierarchicRT(k)
+    qp, qw = make_quadrature_triangle(qdegree)
+    c = np.asarray(sigma).reshape(mesh.ncells, rt.ndofs)
+    div = np.einsum("ci,qi->cq", c, rt.tabulate_div(qp)) / detJ[:, None]
+    if flux_dg is not None:
+        dg = Lagrange(k - 1)
+        gr = dg.tabulate(qp, 1)[1:]                               # [2, q, nd] reference derivatives
+        G = np.asarray(flux_dg).reshape(mesh.ncells, dg.ndofs, 2)
+        # d/dx_i = sum_a K[a, i] d/dX_a
+        div = div + np.einsum("cai,aqd,cdi->cq", K, gr, G)
+    x0 = mesh.x[mesh.cell_nodes[:, 0], :2]
+    xq = x0[:, None, :] + np.einsum("cij,qj->cqi", J, qp)
+    r = f(xq[..., 0], xq[..., 1]) - div
+    ck = np.ones(mesh.ncells) if korn is None else np.asarray(korn)
+    return ck ** 2 * (cell_diameter(mesh) / np.pi) ** 2 * np.abs(detJ) * np.einsum("q,cq->c", qw, r * r)

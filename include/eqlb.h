@@ -270,6 +270,34 @@ int eqlb_ev_estimate(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const double* f
                      const double* flux_dg, const double* rhs_dg, double* cell_div2,
                      double* cell_sig2, double* facet_jump, int32_t memspace, void* stream);
 
+/* Stress estimator terms of demo/elasticity/demo_error_estimation.py:49-148 for an equilibrated stress
+ * delta_sigma = (row 0; row 1), flux_hdiv [2][ncells*k(k+2)] as eqlb_se_equilibrate writes it, per cell:
+ *   cell_energy [ncells]  int_T delta_sigma : A delta_sigma,  A tau = (tau - pi_1/(2 + 2 pi_1) tr(tau) I)/2
+ *                         (:100-102, 109; pi_1 = lambda / mu)
+ *   cell_wsym   [ncells]  int_T (C_K (delta_sigma_01 - delta_sigma_10) / 2)^2            (:108, 121)
+ *   node_asym   [nnodes]  (delta_sigma_01 - delta_sigma_10, hat_n): the weak symmetry condition
+ *                         (python/dolfinx_eqlb/eqlb/check_eqlb_conditions.py:476-521), assembled over the
+ *                         cells of every node in the order of the node -> cell list
+ * korn [ncells]: the cell-wise Korn constants C_K as FluxEqlbSE hands them out (square root taken,
+ * FluxEqlbSE.py:165) or NULL (C_K = 1).  Any output may be NULL.  Quadrature-free (exact). */
+int eqlb_se_estimate_stress(eqlb_mesh_t* mesh, int32_t k, const double* flux_hdiv, const double* korn,
+                            double pi_1, double* cell_energy, double* cell_wsym, double* node_asym,
+                            int32_t memspace, void* stream);
+
+/* Data oscillation per cell,  out [nrhs][ncells] = C_K^2 (h_T / pi)^2 || f - div(sigma) ||^2_L2(T)
+ * (err_osc of demo/poisson/demo_error_estimation.py:96-98 and, with the Korn constant, of
+ * demo/elasticity/demo_error_estimation.py:104-106; h_T = longest edge as dolfinx::mesh::h).
+ *   flux     [nrhs][ncells*k(k+2)]  RT_k coefficients in the broken hierarchic layout
+ *   flux_dg  [nrhs][ncells*k(k+1)]  sigma = flux + flux_dg (semi-explicit result), or NULL: sigma = flux
+ *                                   (a conforming flux, eqlb_ev_set_option "output" = 1)
+ *   qpoints [nq][2], qweights [nq]  rule on the reference triangle (weights sum to 1/2), HOST arrays
+ *   fvalues  [nrhs][ncells][nq]     the un-projected f at the images of the points (as eqlb_project_dg takes)
+ *   korn     [ncells] or NULL       as eqlb_se_estimate_stress
+ * div(sigma) is evaluated exactly (polynomial of P_{k-1} per cell); the rule only integrates f. nq <= 128. */
+int eqlb_oscillation(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const double* flux, const double* flux_dg,
+                     int32_t nq, const double* qpoints, const double* qweights, const double* fvalues,
+                     const double* korn, double* out, int32_t memspace, void* stream);
+
 /* Multi-GPU decomposition by node ownership (the reference has no distributed
  * equilibration, se/reconstruction.hpp:90 loops the owned nodes only): after the local sweep the
  * partial sums of the ghost-cell rows are sent to the owning rank and added there.  DEVICE pointers:

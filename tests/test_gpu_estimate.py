@@ -57,3 +57,99 @@ def test_estimate_detects_violations(k):
     Gc = np.tile(np.array([0.3, -1.1]), mesh.ncells * k * (k + 1) // 2)[None]
     _, _, j0 = cpp.estimate(dm, k, np.zeros_like(x), Gc, f)
     assert j0.max() < 1e-13
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_stress_estimator_terms(k):
+    """eqlb_se_estimate_stress (quadrature-free, per cell) against the numpy statements with quadrature on a
+    perturbed mesh with random local vertex order: energy term, weak-symmetry term with Korn constants, and
+    the assembled weak symmetry residual (check_eqlb_conditions.py:476-521)."""
+    from dolfinx_eqlb_amd import cpp
+    from dolfinx_eqlb_amd.mesh import create_unit_square
+    mesh = create_unit_square(6, shuffle_seed=3, perturb=0.3)
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2, mesh.ncells * k * (k + 2)))
+    korn = 1.0 + rng.random(mesh.ncells)
+    dm = cpp.DeviceMesh(mesh)
+    for pi_1 in (1.0, 50.0):
+        energy, wsym, asym = cpp.estimate_stress(dm, k, x, korn, pi_1)
+        e_ref, w_ref = chk.stress_estimator_terms(mesh, k, x, korn, pi_1)
+        assert np.allclose(energy, e_ref, rtol=1e-11, atol=1e-13 * np.abs(e_ref).max())
+        assert np.allclose(wsym, w_ref, rtol=1e-11, atol=1e-13 * np.abs(w_ref).max())
+        _, L = chk.weak_symmetry_residual(mesh, k, x)
+        assert np.allclose(asym, L, rtol=1e-11, atol=1e-13 * np.abs(L).max())
+    # no Korn constants: C_K = 1; a symmetric stress has no asymmetry terms
+    _, w1, _ = cpp.estimate_stress(dm, k, x, None, 1.0)
+    assert np.allclose(w1, chk.stress_estimator_terms(mesh, k, x, None, 1.0)[1], rtol=1e-11)
+    with pytest.raises(RuntimeError, match="sizes"):
+        cpp.estimate_stress(dm, k, x[:1], None, 1.0)
+
+
+def test_stress_estimator_after_equilibration(oracle_mod):
+    """After the weak-symmetry step the node-wise asymmetry vanishes: the device check agrees with the
+    reference predicate on an equilibrated stress (device equilibrator -> device estimator)."""
+    from test_oracle_stress import stress_case
+    from dolfinx_eqlb_amd import cpp
+    k = 2
+    mesh, ft, G, f = stress_case(5, k, "dirichlet")
+    dm = cpp.DeviceMesh(mesh)
+    eq = cpp.SemiExplicitEquilibrator(dm, k, 2, reconstruct_stress=True)
+    eq.set_boundary(ft)
+    xs = eq.equilibrate_host(G, f)
+    _, _, asym = cpp.estimate_stress(dm, k, xs)
+    assert np.abs(asym).max() < 1e-12
+    assert chk.check_weak_symmetry_condition(mesh, k, xs)
+    plain = cpp.SemiExplicitEquilibrator(dm, k, 2)
+    plain.set_boundary(ft)
+    _, _, asym0 = cpp.estimate_stress(dm, k, plain.equilibrate_host(G, f))
+    assert np.abs(asym0).max() > 1e-4
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+@pytest.mark.parametrize("with_g", [True, False])
+def test_oscillation_term(k, with_g):
+    """eqlb_oscillation: C_K^2 (h/pi)^2 ||f - div(sigma + G)||^2_T with the exact f at quadrature points
+    (demo/poisson/demo_error_estimation.py:96-98) against the numpy statement; with an equilibrated flux the
+    term equals (h/pi)^2 ||f - Pi f||^2_T."""
+    from dolfinx_eqlb_amd import cpp
+    from dolfinx_eqlb_amd.mesh import create_unit_square
+    mesh = create_unit_square(5, shuffle_seed=2, perturb=0.25)
+    rng = np.random.default_rng(5)
+    nrt, nd = k * (k + 2), k * (k + 1) // 2
+    x = rng.standard_normal((2, mesh.ncells * nrt))
+    G = rng.standard_normal((2, mesh.ncells * nd * 2)) if with_g else None
+    korn = 1.0 + rng.random(mesh.ncells)
+
+    def f0(xx, yy):
+        return np.sin(3.0 * xx) * np.exp(yy) + xx * yy
+
+    def f1(xx, yy):
+        return np.cos(2.0 * xx + yy)
+    qdeg = 8
+    qp, qw = make_quadrature_triangle(qdeg)
+    J, detJ, K = chk.cell_geometry(mesh)
+    xq = mesh.x[mesh.cell_nodes[:, 0], :2][:, None, :] + np.einsum("cij,qj->cqi", J, qp)
+    fv = np.stack([f0(xq[..., 0], xq[..., 1]), f1(xq[..., 0], xq[..., 1])])
+    dm = cpp.DeviceMesh(mesh)
+    out = cpp.oscillation(dm, k, x, G, qp, qw, fv, korn)
+    for r, fr in enumerate((f0, f1)):
+        ref = chk.oscillation_term(mesh, k, x[r], None if G is None else G[r], fr, qdeg, korn)
+        assert np.allclose(out[r], ref, rtol=1e-11, atol=1e-13 * ref.max())
+    assert np.allclose(cpp.oscillation(dm, k, x[:1], None if G is None else G[:1], qp, qw, fv[:1])[0],
+                       chk.oscillation_term(mesh, k, x[0], None if G is None else G[0], f0, qdeg), rtol=1e-11)
+
+
+def test_oscillation_of_an_equilibrated_flux(oracle_mod):
+    """div(sigma_eq + G) = Pi f, so the oscillation is the projection error of f, computed independently."""
+    from dolfinx_eqlb_amd import cpp
+    from dolfinx_eqlb_amd.elmtlib.lagrange import Lagrange
+    k = 2
+    mesh, ft, G, f = make_case(6, k, "dirichlet")
+    x = oracle_mod.se_reconstruct(mesh, k, ft, G, f)
+    qp, qw = make_quadrature_triangle(6)
+    tab = Lagrange(k - 1).tabulate(qp)[0]
+    pif = np.einsum("cj,qj->cq", f[0].reshape(mesh.ncells, -1), tab)      # Pi f at the points
+    bump = 0.1 * np.sin(np.arange(mesh.ncells * qw.size)).reshape(mesh.ncells, -1)
+    out = cpp.oscillation(cpp.DeviceMesh(mesh), k, x, G, qp, qw, (pif + bump)[None])
+    ref = (chk.cell_diameter(mesh) / np.pi) ** 2 * np.abs(chk.cell_geometry(mesh)[1]) * (bump ** 2 @ qw)
+    assert np.allclose(out[0], ref, rtol=1e-9, atol=1e-12 * ref.max())

@@ -55,6 +55,10 @@ def tables_exact(k, deg):
             S[0][i][j] = P.integrate_triangle(P.mul(xi, xj))
             S[1][i][j] = P.integrate_triangle(P.mul(xi, yj)) + P.integrate_triangle(P.mul(yi, xj))
             S[2][i][j] = P.integrate_triangle(P.mul(yi, yj))
+    # component-wise products for the stress estimator (tr^2, asymmetry): SU0 = int phi_i^x phi_j^x,
+    # SU1 = int phi_i^x phi_j^y (not symmetrised), SU2 = int phi_i^y phi_j^y
+    SU = [[[P.integrate_triangle(P.mul(rt.basis[i][a], rt.basis[j][b])) for j in range(nrt)] for i in range(nrt)]
+          for (a, b) in ((0, 0), (0, 1), (1, 1))]
     F = [[[[Fraction(0)] * k for _ in range(nd)] for _ in range(3)] for _ in range(3)]
     for f in range(3):
         xs, ys = ert.FACET_PARAM[f]
@@ -131,7 +135,8 @@ def tables_exact(k, deg):
             for d in range(nd)] for i in range(nrt)]
     MPS = [[P.integrate_triangle(P.mul(dg.basis[d], dg.basis[e])) for e in range(nd)] for d in range(nd)]
     return dict(k=k, deg=deg, nrt=nrt, nd=nd, nq=len(monos), S=S, F=F, H=H, D=D, B=B, TE=TE, WQ=WQ,
-                V=V, VQ=VQ, HB=HB, HG=HG, WGF=WGF, WG=WG, DM=DM, GMI=GMI, F0=F0, MRD=MRD, MPS=MPS)
+                V=V, VQ=VQ, HB=HB, HG=HG, WGF=WGF, WG=WG, DM=DM, GMI=GMI, F0=F0, MRD=MRD, MPS=MPS, SU=SU,
+                monos=monos)
 
 
 def _local_maps(k, B, fm, fp, rev):
@@ -298,6 +303,10 @@ def emit(path):
         arr("F0", (3, nd, k), t["F0"])
         arr("MRD", (nrt, nd, 2), t["MRD"])
         arr("MPS", (nd, nd), t["MPS"])
+        arr("SU", (3, nrt, nrt), t["SU"])
+        lines.append("  // exponents (l, m) of the monomials x^l y^m the NQ divergence moments are taken with")
+        lines.append(f"  static constexpr int MONO_X[{nq}] = {{{', '.join(str(l) for l, _ in t['monos'])}}};")
+        lines.append(f"  static constexpr int MONO_Y[{nq}] = {{{', '.join(str(m) for _, m in t['monos'])}}};")
         lines.append("};")
         lines.append("")
     # Lagrange P_d (Basix numbering, equispaced): monomial coefficients and inverse mass matrix
