@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+VALU_NS_PER_INSTRUCTION = 2.0  # measured, see roofline.valu_floor_ms below
 HEADLINE_METRIC = "equilibrated patches/s (fp64) on 1M-tri Poisson k=2; L2 flux-divergence residual"
 
 
@@ -56,6 +57,7 @@ def parse():
                     help="two rows + weak symmetry (BASELINE configs[3]); not the headline")
     ap.add_argument("--ev", action="store_true",
                     help="constrained-minimisation equilibrator (FluxEqlbEV, configs[2]); not the headline")
+    ap.add_argument("--tile-cells", type=int, default=0, help="cells per tile of the tiled launch (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shuffle", type=int, default=None, help="seed for random local vertex order")
     return ap.parse_args()
@@ -186,6 +188,8 @@ def main():
         eq = cpp.ConstrainedMinEquilibrator(dmesh, k, nrhs)
         fused = True
         eq.set_option("accumulate", args.accumulate)
+        if args.tile_cells:
+            eq.set_option("tile_cells", args.tile_cells)
         eq.set_boundary(ft, node_mask=part.node_mask)
         nout = eq.ndofs
     else:
@@ -200,6 +204,8 @@ def main():
         fused = (bool(args.fused) and args.solver in (None, 1)) or args.scatter == 2
         eq.set_option("fused", int(fused))
         eq.set_option("accumulate", args.accumulate)
+        if args.tile_cells:
+            eq.set_option("tile_cells", args.tile_cells)
         if world > 1 and args.scatter == 2:
             eq.set_priority_cells(part.send_cells)  # their tiles run first: halo exchange behind the rest
         eq.set_boundary(ft, node_mask=part.node_mask)
@@ -425,8 +431,11 @@ def main():
         out["roofline"]["note"] = roof_note
     if pmc.get("insts_valu"):
         # the binding resource of this kernel is VALU issue + latency, not HBM:
-        # issue floor = wave-level VALU instructions x 4 cycles / (1024 SIMDs x 2.4 GHz)
-        floor_ms = pmc["insts_valu"] * 4.0 / (1024 * 2.4e9) * 1e3
+        # issue floor = wave-level VALU instructions / 1024 SIMDs x 2.0 ns, the MEASURED issue time of a
+        # wave64 instruction on one SIMD of this part at 4 waves/SIMD (fp64 FMA 2.10 ns, fp64 MUL / ADD and
+        # 32-bit DPP moves 1.91 - 1.98 ns: tools/microbench/valu_rate.hip, profiles/r02_valu_rate.txt) -
+        # i.e. 4 cycles at the ~2.0 GHz the chip holds under fp64 load, not at the 2.4 GHz of the data sheet
+        floor_ms = pmc["insts_valu"] / 1024.0 * VALU_NS_PER_INSTRUCTION * 1e-6
         out["roofline"]["valu_floor_ms"] = floor_ms
         out["roofline"]["valu_frac"] = floor_ms / kernels_ms[kname] if kernels_ms[kname] > 0 else None
         out["roofline"]["valu_source"] = pmc.get("source")

@@ -230,6 +230,7 @@ struct eqlb_se
   int scatter_last = EQLB_SCATTER_SLOTS; // scatter mode the last equilibrate call resolved to
   int mode = 0;                     // 1: constrained-minimisation (EV) patch problems
   int ev_output = 0;                // EV: 0 conforming DOFs, 1 broken hierarchic RT_k layout
+  int tile_cells_user = 0;          // option "tile_cells": cells per tile of the tiled launch (0 = automatic)
   int ev_bv_hier = 0;               // EV: boundary values in the hierarchic basis although a basis transform is set
   int32_t* ev_cell_dofs = nullptr;  // EV: device copy of the caller's dofmap or nullptr (default)
   int64_t ev_ndofs = 0;             // EV: number of conforming flux DOFs

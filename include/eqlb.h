@@ -111,7 +111,8 @@ void eqlb_se_destroy(eqlb_se_t* handle);
  * see eqlb_se_set_priority_cells), "accumulate" (1, default: flux_hdiv += result as the reference does,
  * se/solve_patch_semiexplt.hpp:1157-1160, which assumes a zero-initialised output; 0: flux_hdiv = result,
  * the old values are neither read nor uploaded - every DOF of every cell is written; not with the
- * atomic scatter). */
+ * atomic scatter), "tile_cells" (cells per tile of the tiled launch, 0 = automatic; capped by the LDS of a
+ * workgroup; applies to the next eqlb_se_set_boundary - a tuning knob). */
 int eqlb_se_set_option(eqlb_se_t* handle, const char* key, int32_t value);
 
 /*
