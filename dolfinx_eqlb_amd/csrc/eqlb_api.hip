@@ -1169,7 +1169,7 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
   const size_t s_x = ev_conf ? (size_t)h->ev_ndofs : s_slot, n_x = (size_t)h->nrhs * s_x;
   if (!h->accumulate && scatter_eff == EQLB_SCATTER_ATOMIC)
     return fail(EQLB_ERR_UNSUPPORTED, "\"accumulate\" = 0 is not available with the atomic scatter");
-  if (h->mode == 1 && (scatter_eff == EQLB_SCATTER_ATOMIC || h->solver != EQLB_SOLVER_SHUFFLE))
+  if (h->mode == 1 && (scatter_eff == EQLB_SCATTER_ATOMIC || (h->solver != EQLB_SOLVER_SHUFFLE && h->k != 4)))
     return fail(EQLB_ERR_UNSUPPORTED, "EV equilibration runs with the shuffle solver (tiled or slot scatter)");
 
   std::vector<const double*> d_g(g_in, g_in + h->nrhs), d_f(f_in, f_in + h->nrhs);
@@ -1260,7 +1260,7 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
       HIP_TRY(hipMemset(h->slots, 0, n_slot * 3 * sizeof(double)));
     }
     eqlb::SeArgs as = a;
-    if (h->mode == 1 || (h->fused && h->solver == EQLB_SOLVER_SHUFFLE))
+    if ((h->mode == 1 && h->k <= 3) || (h->fused && h->solver == EQLB_SOLVER_SHUFFLE))
     {
       // all bins in one launch; timing slot 0 holds the fused kernel
       eqlb::FusedBins fb{};
@@ -1300,7 +1300,7 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
         for (int r = 0; r < h->nrhs; ++r)
         {
           select_rhs(as, r, true);
-          const int st = eqlb::launch_se_patch(h->k, h->deg, h->bins[b].P, h->solver, EQLB_SCATTER_SLOTS, as, stream);
+          const int st = eqlb::launch_se_patch(h->k, h->deg, h->bins[b].P, h->solver, EQLB_SCATTER_SLOTS, as, stream, h->mode);
           if (st)
             return fail(st, "patch kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
         }
@@ -1532,7 +1532,7 @@ double eqlb_se_last_kernel_ms(const eqlb_se_t* h, int32_t which)
     return 0.0;
   if (which == eqlb::MAX_BINS + 1 && !h->stress)
     return 0.0;
-  const bool fused_run = h->mode == 1 || h->scatter_last == EQLB_SCATTER_TILED
+  const bool fused_run = (h->mode == 1 && h->k <= 3) || h->scatter_last == EQLB_SCATTER_TILED
                          || (h->fused && h->solver == EQLB_SOLVER_SHUFFLE);
   if (which < eqlb::MAX_BINS && ((fused_run && which != 0) || (!fused_run && h->bins[which].npatch == 0)))
     return 0.0;

@@ -167,9 +167,11 @@ struct Sizes
   static constexpr int NHG = HROW, NWG = NCOMBO * NH * ND * 2, NEV = NHG + NWG; // HG padded like a row of H
   static constexpr int OFF_HG = OFF_VQ + NVQT;
   // workgroup size: as many waves as fit a 64 KiB LDS budget for the dense tiles (at least one)
+  // k = 4 (dense LDS solver): the tables and the patch tiles leave no room for WG, it is read from global memory
+  static constexpr int NEV_LDS = (K >= 4) ? NHG : NEV;
   static constexpr int lds_doubles(int block, int solver, int mode = 0)
   {
-    return NTAB + (mode ? NEV : 0) + ((K > 1 && solver == 0) ? (block / P) * LDS_GROUP : 0);
+    return NTAB + (mode ? NEV_LDS : 0) + ((K > 1 && solver == 0) ? (block / P) * LDS_GROUP : 0);
   }
   static constexpr int block_of(int solver)
   {

@@ -200,8 +200,11 @@ void launch_ev_boundary_to_broken(const DeviceMesh& m, int k, int nrhs, const in
   else if (k == 2)
     hipLaunchKernelGGL(k_ev_boundary_to_broken<2>, grid, block, 0, stream, m.ncells, m.nfacets, nrhs,
                        m.cell_facets, m.facet_perm, cell_dofs, ndofs, bv_conf, bv_broken, facet_maps);
-  else
+  else if (k == 3)
     hipLaunchKernelGGL(k_ev_boundary_to_broken<3>, grid, block, 0, stream, m.ncells, m.nfacets, nrhs,
+                       m.cell_facets, m.facet_perm, cell_dofs, ndofs, bv_conf, bv_broken, facet_maps);
+  else
+    hipLaunchKernelGGL(k_ev_boundary_to_broken<4>, grid, block, 0, stream, m.ncells, m.nfacets, nrhs,
                        m.cell_facets, m.facet_perm, cell_dofs, ndofs, bv_conf, bv_broken, facet_maps);
 }
 
@@ -219,8 +222,11 @@ void launch_ev_reduce(const DeviceMesh& m, int k, int nrhs, const int32_t* cell_
     else if (k == 2)
       hipLaunchKernelGGL(k_ev_reduce_basis<2>, g2, b2, 0, stream, m.ncells, m.nfacets, nrhs, m.cell_facets, m.facet_perm,
                          m.facet_cells_off, m.facet_cells, cell_dofs, ndofs, slots, x, accumulate, basis_C, basis_R);
-    else
+    else if (k == 3)
       hipLaunchKernelGGL(k_ev_reduce_basis<3>, g2, b2, 0, stream, m.ncells, m.nfacets, nrhs, m.cell_facets, m.facet_perm,
+                         m.facet_cells_off, m.facet_cells, cell_dofs, ndofs, slots, x, accumulate, basis_C, basis_R);
+    else
+      hipLaunchKernelGGL(k_ev_reduce_basis<4>, g2, b2, 0, stream, m.ncells, m.nfacets, nrhs, m.cell_facets, m.facet_perm,
                          m.facet_cells_off, m.facet_cells, cell_dofs, ndofs, slots, x, accumulate, basis_C, basis_R);
     return;
   }
@@ -233,8 +239,11 @@ void launch_ev_reduce(const DeviceMesh& m, int k, int nrhs, const int32_t* cell_
   else if (k == 2)
     hipLaunchKernelGGL(k_ev_reduce<2>, grid, block, 0, stream, m.ncells, m.nfacets, nrhs, m.cell_facets,
                        m.facet_perm, m.facet_cells_off, m.facet_cells, cell_dofs, ndofs, slots, x, accumulate);
-  else
+  else if (k == 3)
     hipLaunchKernelGGL(k_ev_reduce<3>, grid, block, 0, stream, m.ncells, m.nfacets, nrhs, m.cell_facets,
+                       m.facet_perm, m.facet_cells_off, m.facet_cells, cell_dofs, ndofs, slots, x, accumulate);
+  else
+    hipLaunchKernelGGL(k_ev_reduce<4>, grid, block, 0, stream, m.ncells, m.nfacets, nrhs, m.cell_facets,
                        m.facet_perm, m.facet_cells_off, m.facet_cells, cell_dofs, ndofs, slots, x, accumulate);
 }
 

@@ -159,7 +159,7 @@ void launch_cell_geometry(int32_t ncells, const double* x, const int32_t* cell_n
                           double* cellJ, hipStream_t stream);
 // returns 0 or EQLB_ERR_UNSUPPORTED
 int launch_se_patch(int k, int deg, int P, int solver, int scatter, const SeArgs& a,
-                    hipStream_t stream);
+                    hipStream_t stream, int mode = 0);
 int launch_se_patch_fused(int k, int deg, int scatter, const SeArgs& a, const FusedBins& fb,
                           hipStream_t stream);
 int launch_se_patch_tiled(int k, int deg, int mode, const SeArgs& a, const TileArgs& t, hipStream_t stream);

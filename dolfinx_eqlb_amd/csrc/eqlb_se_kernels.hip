@@ -168,9 +168,10 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   double* sWQ = sTE + Z::NTET;  // [NCOMBO][3][NH][NCOL]
   double* sHB = sWQ + Z::NWQT;                    // [3][3][K][K]
   double* sHG = sHB + Z::NHB;                     // MODE 1: [ND][NQ]
-  double* sWG = sHG + Z::NHG;                     // MODE 1: [NCOMBO][NH][ND][2]
+  // MODE 1: [NCOMBO][NH][ND][2]; RT_4: straight from the table buffer in global memory (Sizes::NEV_LDS)
+  const double* sWG = (K >= 4) ? a.tables + Z::OFF_HG + Z::NHG : sHG + Z::NHG;
   (void)sWG;
-  double* sA = sHB + Z::NHB + (MODE ? Z::NEV : 0); // SOLVER 0: per-group tiles
+  double* sA = sHB + Z::NHB + (MODE ? Z::NEV_LDS : 0); // SOLVER 0: per-group tiles
   (void)sA;
 
   int tid_ = threadIdx.x;
@@ -189,7 +190,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
     for (int i = tid; i < Z::NTAB; i += BLOCK)
       lds[i] = a.tables[Z::NS + i];
     if constexpr (MODE == 1)
-      for (int i = tid; i < Z::NEV; i += BLOCK)
+      for (int i = tid; i < Z::NEV_LDS; i += BLOCK)
         sHG[i] = a.tables[Z::OFF_HG + i];
     __syncthreads();
   }
@@ -1485,11 +1486,11 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 }
 
 // one bin per launch (any solver)
-template <int K, int DEG, int P, int SOLVER, int SCATTER>
+template <int K, int DEG, int P, int SOLVER, int SCATTER, int MODE = 0>
 __global__ void __launch_bounds__((Sizes<K, DEG, P>::block_of(SOLVER))) k_se_patch(const SeArgs a)
 {
   extern __shared__ __align__(16) double lds[];
-  se_patch_body<K, DEG, P, SOLVER, SCATTER, Sizes<K, DEG, P>::block_of(SOLVER)>(a, blockIdx.x, lds);
+  se_patch_body<K, DEG, P, SOLVER, SCATTER, Sizes<K, DEG, P>::block_of(SOLVER), MODE>(a, blockIdx.x, lds);
 }
 
 // all bins in ONE launch (register solver): blocks [start[b], start[b+1]) run the P = 4 << b body,
@@ -2132,15 +2133,15 @@ int launch_reduce_slots(int nrt, int32_t ncells, int32_t nrhs, const double* slo
 }
 
 // ---- dispatch -------------------------------------------------------------------------------------
-template <int K, int DEG, int P, int SOLVER, int SCATTER>
+template <int K, int DEG, int P, int SOLVER, int SCATTER, int MODE = 0>
 static int launch_t(const SeArgs& a, hipStream_t stream)
 {
   using Z = Sizes<K, DEG, P>;
   constexpr int BLOCK = Z::block_of(SOLVER);
-  const size_t lds_bytes = sizeof(double) * (size_t)Z::lds_doubles(BLOCK, SOLVER);
+  const size_t lds_bytes = sizeof(double) * (size_t)Z::lds_doubles(BLOCK, SOLVER, MODE);
   if (lds_bytes > 160 * 1024)
     return EQLB_ERR_UNSUPPORTED;
-  auto kern = k_se_patch<K, DEG, P, SOLVER, SCATTER>;
+  auto kern = k_se_patch<K, DEG, P, SOLVER, SCATTER, MODE>;
   if (lds_bytes > 64 * 1024)
   {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -2235,20 +2236,28 @@ int launch_se_patch_fused(int k, int deg, int scatter, const SeArgs& a, const Fu
 }
 
 // k = 4 (three interior unknowns per cell): dense LDS Cholesky only, patches of up to 8 facets
-static int launch_k4(int P, int solver, int scatter, const SeArgs& a, hipStream_t stream)
+static int launch_k4(int P, int solver, int scatter, const SeArgs& a, hipStream_t stream, int mode)
 {
   if (solver != EQLB_SOLVER_LDS_CHOLESKY || (P != 4 && P != 8))
     return EQLB_ERR_UNSUPPORTED;
+  if (mode == 1) // constrained-minimisation patch problems (slots only)
+  {
+    if (scatter != EQLB_SCATTER_SLOTS)
+      return EQLB_ERR_UNSUPPORTED;
+    return (P == 4) ? launch_t<4, 3, 4, 0, 0, 1>(a, stream) : launch_t<4, 3, 8, 0, 0, 1>(a, stream);
+  }
   if (scatter == EQLB_SCATTER_SLOTS)
     return (P == 4) ? launch_t<4, 3, 4, 0, 0>(a, stream) : launch_t<4, 3, 8, 0, 0>(a, stream);
   return (P == 4) ? launch_t<4, 3, 4, 0, 1>(a, stream) : launch_t<4, 3, 8, 0, 1>(a, stream);
 }
 
 int launch_se_patch(int k, int deg, int P, int solver, int scatter, const SeArgs& a,
-                    hipStream_t stream)
+                    hipStream_t stream, int mode)
 {
   if (k == 4 && deg == 3)
-    return launch_k4(P, solver, scatter, a, stream);
+    return launch_k4(P, solver, scatter, a, stream, mode);
+  if (mode != 0)
+    return EQLB_ERR_UNSUPPORTED; // k <= 3: the EV patch problems run on the fused / tiled launches
   if (k == 1 && deg == 0)
     return launch_kd<1, 0>(P, solver, scatter, a, stream);
   if (k == 2 && deg == 1)

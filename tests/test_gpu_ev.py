@@ -19,7 +19,7 @@ def _close(x, ref):
     return np.abs(x - ref).max() <= RTOL * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("k", [1, 2, 3])
+@pytest.mark.parametrize("k", [1, 2, 3, 4])
 @pytest.mark.parametrize("bc", ["dirichlet", "neumann_lt", "neumann_bottom"])
 @pytest.mark.parametrize("shuffle", [77, None])
 def test_ev_matches_oracle(oracle_mod, k, bc, shuffle):
@@ -45,7 +45,7 @@ def test_ev_matches_oracle(oracle_mod, k, bc, shuffle):
     assert res < 1e-10 * nrm
 
 
-@pytest.mark.parametrize("k", [1, 2, 3])
+@pytest.mark.parametrize("k", [1, 2, 3, 4])
 def test_ev_inhomogeneous_bc_and_dofmap(oracle_mod, k):
     from dolfinx_eqlb_amd import cpp
 
@@ -190,7 +190,7 @@ def _transform_reference(mesh, k, xb, C, R, cd, nd):
     return out
 
 
-@pytest.mark.parametrize("k,sc", [(1, 2), (2, 2), (3, 2), (2, 0), (3, 0)])
+@pytest.mark.parametrize("k,sc", [(1, 2), (2, 2), (3, 2), (2, 0), (3, 0), (4, 0)])
 def test_ev_basis_transform(oracle_mod, k, sc):
     """Change of basis of the conforming output (the hook through which a DOLFINx-side adapter asks for
     Basix RT_k coefficients; parity of that basis itself is unpinned - no Basix here): a random target

@@ -25,7 +25,7 @@ def kkt_sweep(mesh, k, ft, G, f, neumann_flux=None):
     return x.reshape(-1), worst
 
 
-@pytest.mark.parametrize("k", [1, 2, 3])
+@pytest.mark.parametrize("k", [1, 2, 3, 4])
 @pytest.mark.parametrize("bc", ["dirichlet", "neumann_lt", "neumann_bottom"])
 def test_ev_oracle_matches_independent_minimiser(oracle_mod, k, bc):
     mesh = create_unit_square(3, shuffle_seed=11, perturb=0.25)
