@@ -720,8 +720,7 @@ int eqlb_se_create(eqlb_mesh_t* mesh, int32_t k, int32_t degree_dg, int32_t nrhs
   }
   (void)estimate_korn;
   std::vector<double> tab;
-  if (eqlb::fill_tables_host(k, degree_dg, tab) != 0 || degree_dg != k - 1 || k > 4
-      || (k == 4 && reconstruct_stress))
+  if (eqlb::fill_tables_host(k, degree_dg, tab) != 0 || degree_dg != k - 1 || k > 4)
     return fail(EQLB_ERR_UNSUPPORTED, "RT_%d with DG_%d data%s is not in this build", k, degree_dg,
                 reconstruct_stress ? " (stress)" : "");
   eqlb_se* h = new eqlb_se();
@@ -1650,7 +1649,7 @@ static int estimate_impl(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const doubl
                          double* cell_sig2, double* facet_jump, int32_t memspace, void* stream_,
                          double alpha, double beta)
 {
-  if (!mesh || !flux_hdiv || !flux_dg || !rhs_dg || nrhs < 1 || k < 1 || k > 3)
+  if (!mesh || !flux_hdiv || !flux_dg || !rhs_dg || nrhs < 1 || k < 1 || k > 4)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_estimate: invalid argument");
   const eqlb::DeviceMesh& m = mesh->m;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -1763,7 +1762,7 @@ int eqlb_se_estimate_stress(eqlb_mesh_t* mesh, int32_t k, const double* flux_hdi
                             double pi_1, double* cell_energy, double* cell_wsym, double* node_asym,
                             int32_t memspace, void* stream_)
 {
-  if (!mesh || !flux_hdiv || k < 1 || k > 3 || !(pi_1 > -1.0))
+  if (!mesh || !flux_hdiv || k < 1 || k > 4 || !(pi_1 > -1.0))
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_estimate_stress: invalid argument");
   if (memspace != EQLB_MEM_DEVICE && memspace != EQLB_MEM_HOST)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_estimate_stress: unknown memory space");
@@ -1797,7 +1796,7 @@ int eqlb_oscillation(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const double* f
                      int32_t nq, const double* qpoints, const double* qweights, const double* fvalues,
                      const double* korn, double* out, int32_t memspace, void* stream_)
 {
-  if (!mesh || !flux || !qpoints || !qweights || !fvalues || !out || nrhs < 1 || k < 1 || k > 3 || nq < 1
+  if (!mesh || !flux || !qpoints || !qweights || !fvalues || !out || nrhs < 1 || k < 1 || k > 4 || nq < 1
       || nq > 128)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_oscillation: invalid argument");
   if (memspace != EQLB_MEM_DEVICE && memspace != EQLB_MEM_HOST)

@@ -261,6 +261,8 @@ int launch_estimate(const DeviceMesh& m, int k, int nrhs, const double* x_eq, co
     return launch_estimate_k<2>(m, nrhs, x_eq, flux_dg, rhs_dg, div2, sig2, jump, alpha, beta, stream);
   if (k == 3)
     return launch_estimate_k<3>(m, nrhs, x_eq, flux_dg, rhs_dg, div2, sig2, jump, alpha, beta, stream);
+  if (k == 4)
+    return launch_estimate_k<4>(m, nrhs, x_eq, flux_dg, rhs_dg, div2, sig2, jump, alpha, beta, stream);
   return EQLB_ERR_UNSUPPORTED;
 }
 
@@ -418,6 +420,8 @@ int launch_estimate_stress(const DeviceMesh& m, const int32_t* node_cells, int k
     return launch_estimate_stress_k<2>(m, node_cells, x0, x1, korn, pi_1, energy, wsym, node_asym, stream);
   if (k == 3)
     return launch_estimate_stress_k<3>(m, node_cells, x0, x1, korn, pi_1, energy, wsym, node_asym, stream);
+  if (k == 4)
+    return launch_estimate_stress_k<4>(m, node_cells, x0, x1, korn, pi_1, energy, wsym, node_asym, stream);
   return EQLB_ERR_UNSUPPORTED;
 }
 
@@ -550,6 +554,8 @@ int launch_oscillation(const DeviceMesh& m, int k, int nrhs, const double* x_eq,
     return launch_oscillation_k<2>(m, nrhs, x_eq, flux_dg, nq, qpoints, qweights, fvalues, korn, out, stream);
   if (k == 3)
     return launch_oscillation_k<3>(m, nrhs, x_eq, flux_dg, nq, qpoints, qweights, fvalues, korn, out, stream);
+  if (k == 4)
+    return launch_oscillation_k<4>(m, nrhs, x_eq, flux_dg, nq, qpoints, qweights, fvalues, korn, out, stream);
   return EQLB_ERR_UNSUPPORTED;
 }
 

@@ -1200,6 +1200,10 @@ int launch_se_weaksym(int k, int P, bool no_flux_bcs, const SeArgs& a, hipStream
     return launch_ws_k<2>(P, a, stream);
   if (k == 3)
     return launch_ws_k<3>(P, a, stream);
+  if (k == 4 && P == 4) // RT_4: patches of up to 8 facets, like its row sweeps
+    return launch_ws_t<4, 4>(a, stream);
+  if (k == 4 && P == 8)
+    return launch_ws_t<4, 8>(a, stream);
   return EQLB_ERR_UNSUPPORTED;
 }
 

@@ -96,8 +96,8 @@ void eqlb_mesh_destroy(eqlb_mesh_t* mesh);
  * the first two RHS are the rows of a stress tensor and the weak symmetry condition is imposed
  * patch-wise after the row-wise equilibration (se/solve_patch_weaksym.hpp:59-233), including the
  * grouped boundary patches for RT_2 with flux BCs on the stress (se/reconstruction.hpp:170-234;
- * groups that overlap are refused with EQLB_ERR_UNSUPPORTED).  k <= 3 (k = 4 without stress, on
- * patches of up to 8 facets).  estimate_korn is accepted for symmetry with the
+ * groups that overlap are refused with EQLB_ERR_UNSUPPORTED).  k <= 4 (k = 4, the upper end of the
+ * reference's test range: on patches of up to 8 facets, dense LDS solver, slot path; also stress and EV).  estimate_korn is accepted for symmetry with the
  * reference constructor (the estimate itself is requested per call, see below).
  */
 int eqlb_se_create(eqlb_mesh_t* mesh, int32_t k, int32_t degree_dg, int32_t nrhs,

@@ -8,7 +8,8 @@ from test_oracle_stress import asym_moments, stress_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("k,bc", [(2, "dirichlet"), (3, "dirichlet"), (3, "neumann_lt"),
+@pytest.mark.parametrize("k,bc", [(2, "dirichlet"), (3, "dirichlet"), (3, "neumann_lt"), (4, "dirichlet"),
+                                  (4, "neumann_lt"),
                                   (2, "neumann_bottom"), (3, "neumann_bottom"), (2, "neumann_lt")])
 def test_stress_matches_oracle(oracle_mod, k, bc):
     from dolfinx_eqlb_amd import cpp

@@ -50,7 +50,7 @@ def stress_case(n, k, bc, shuffle=5):
 
 
 @pytest.mark.parametrize("k,bc", [(2, "dirichlet"), (3, "dirichlet"), (3, "neumann_lt"), (3, "neumann_bottom"),
-                                  (2, "neumann_bottom"), (2, "neumann_lt")])
+                                  (2, "neumann_bottom"), (2, "neumann_lt"), (4, "dirichlet"), (4, "neumann_lt")])
 def test_stress_conditions(oracle_mod, k, bc):
     """(2, neumann_lt): the corner node between the two flux-BC sides has two cells -> grouped with
     the adjacent internal patch (se/reconstruction.hpp:170-234)."""
@@ -66,7 +66,7 @@ def test_stress_conditions(oracle_mod, k, bc):
         assert chk.boundary_flux_residual(mesh, k, xs[r], G[r], np.nonzero(ft[r] == 2)[0]) < 1e-11
 
 
-@pytest.mark.parametrize("k,bc", [(2, "dirichlet"), (3, "neumann_lt")])
+@pytest.mark.parametrize("k,bc", [(2, "dirichlet"), (3, "neumann_lt"), (4, "neumann_bottom")])
 def test_patch_corrections_are_constrained_minimisers(oracle_mod, k, bc):
     mesh, ft, G, f = stress_case(3, k, bc)
     rt = ert.HierarchicRT(k)
