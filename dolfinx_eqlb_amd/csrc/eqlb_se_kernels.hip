@@ -134,20 +134,10 @@ __device__ __forceinline__ void ldrow16(const double* p, double (&r)[N])
   }
 }
 
-// descriptors of one lane of a wave-block, fetched one wave-block ahead by the tiled launch
-struct WbDesc
-{
-  int32_t cell_raw;
-  uint32_t info;
-  int n;
-  uint8_t flag0, flag;
-};
-
-template <int K, int DEG, int P, int SOLVER, int SCATTER, int BLOCK, int MODE = 0, bool FULL = false, bool PRE = false>
+template <int K, int DEG, int P, int SOLVER, int SCATTER, int BLOCK, int MODE = 0, bool FULL = false>
 __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t block_id, double* lds,
                                               const bool tables_staged = false,
-                                              const int64_t lane_index = -1, double* tile_slots = nullptr,
-                                              const WbDesc* pre = nullptr)
+                                              const int64_t lane_index = -1, double* tile_slots = nullptr)
 {
   using Z = Sizes<K, DEG, P>;
   constexpr int KB = Z::KB, NADD = Z::NADD, NDIV = Z::NDIV, NRT = Z::NRT, ND = Z::ND, NQ = Z::NQ;
@@ -182,7 +172,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 #ifndef EQLB_OPAQUE_K3
 #define EQLB_OPAQUE_K3 1 // RT_3 tiled: 219 -> 207 VGPRs, 0.345 -> 0.338 ms at 1M triangles
 #endif
-  if constexpr (SCATTER == 2 && (MODE == 1 || PRE || (EQLB_OPAQUE_K3 && K >= 3)))
+  if constexpr (SCATTER == 2 && (MODE == 1 || (EQLB_OPAQUE_K3 && K >= 3)))
     asm volatile("" : "+v"(tid_));
   const int tid = tid_;
   if (!tables_staged)
@@ -213,16 +203,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   int32_t cell_raw = -1;
   uint32_t info = 0u;
   uint8_t flag0 = (uint8_t)PFLAG_INTERIOR, flag = (uint8_t)0;
-  if constexpr (PRE)
-  {
-    // (already in registers: loaded while the previous wave-block of this wave was being solved)
-    n = pre->n;
-    cell_raw = pre->cell_raw;
-    info = pre->info;
-    flag0 = pre->flag0;
-    flag = pre->flag;
-  }
-  else if (pvalid)
+  if (pvalid)
   {
     n = (int)a.pn[patch];
     cell_raw = a.slot_cell[slot];
@@ -1738,94 +1719,6 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
 #ifndef EQLB_EXP_FULLONLY
 #define EQLB_EXP_FULLONLY 0
 #endif
-#ifndef EQLB_TILE_PREFETCH
-#define EQLB_TILE_PREFETCH 0 // measured: 5 % SLOWER on every configuration (RT_2 0.0935 -> 0.0985 ms, RT_3 0.346 -> 0.360, RT_1 0.0415 -> 0.046)
-#endif
-#if EQLB_TILE_PREFETCH && !defined(EQLB_EXP_NOBODY)
-  // The wave-blocks of the tile in bin order, dealt to the waves round-robin.  A wave-block costs two dependent
-  // memory round trips (descriptors, then J / G / f of the cell) in front of ~2 400 cycles of arithmetic, and
-  // at 2-4 waves per SIMD that latency is what the kernel waits for: the descriptors of a wave's NEXT
-  // wave-block are loaded while the current one is solved (5 registers), so only one round trip stays exposed.
-  {
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    int lane_ = threadIdx.x & 63;
-    asm volatile("" : "+v"(lane_)); // opaque: no lane predicate leaves the loop below
-    const int lane = lane_;
-    constexpr int NW = TILE_THREADS / 64;
-    int nwb[MAX_BINS], total = 0;
-#pragma unroll
-    for (int b = 0; b < MAX_BINS; ++b)
-    {
-      nwb[b] = (td.npatch[b] * (4 << b) + 63) >> 6;
-      total += nwb[b];
-    }
-    int cb = 0, cu = 0; // bin and wave-block within the bin of the descriptors in `cur`
-    auto fetch = [&](int g, int& b, int& u, WbDesc& d) {
-      b = 0;
-      u = g;
-#pragma unroll
-      for (int i = 0; i + 1 < MAX_BINS; ++i)
-        if (b == i && u >= nwb[i])
-        {
-          u -= nwb[i];
-          b = i + 1;
-        }
-      const int64_t tl = (int64_t)u * 64 + lane;
-      const int64_t pl = tl >> (2 + b);
-      d.n = 0;
-      d.cell_raw = -1;
-      d.info = 0u;
-      d.flag0 = (uint8_t)PFLAG_INTERIOR;
-      d.flag = (uint8_t)0;
-      if (pl < td.npatch[b])
-      {
-        const int64_t slot = td.slot_start[b] + tl, patch = td.patch_start[b] + pl;
-        d.n = (int)a0.pn[patch];
-        d.cell_raw = a0.slot_cell[slot];
-        d.info = a0.slot_info[slot];
-        d.flag0 = a0.pflag[patch];
-        d.flag = a0.pflag[(int64_t)a0.rhs * a0.npatch_total + patch];
-      }
-    };
-    WbDesc cur;
-    if (wave < total)
-      fetch(wave, cb, cu, cur);
-    SeArgs a = a0;
-    for (int g = wave; g < total; g += NW)
-    {
-      WbDesc nxt;
-      int nb = 0, nu = 0;
-      if (g + NW < total)
-        fetch(g + NW, nb, nu, nxt);
-      a.npatch = td.npatch[cb];
-      a.slot_offset = td.slot_start[cb];
-      a.patch_offset = td.patch_start[cb];
-      const int64_t li = (int64_t)cu * 64 + lane;
-#define EQLB_TILE_CASE(B, PP)                                                                                  \
-  case B:                                                                                                      \
-  {                                                                                                            \
-    constexpr bool SPEC = PP <= 8 && K >= 2;                                                                   \
-    if (SPEC && cu < ((td.nfull[B] * PP) >> 6))                                                                \
-      se_patch_body<K, DEG, PP, EQLB_TILE_SOLVER, 2, 64, MODE, SPEC, true>(a, 0, lds, true, li, sSlots, &cur); \
-    else                                                                                                       \
-      se_patch_body<K, DEG, PP, EQLB_TILE_SOLVER, 2, 64, MODE, false, true>(a, 0, lds, true, li, sSlots, &cur); \
-    break;                                                                                                     \
-  }
-      switch (cb)
-      {
-        EQLB_TILE_CASE(0, 4)
-        EQLB_TILE_CASE(1, 8)
-        EQLB_TILE_CASE(2, 16)
-        EQLB_TILE_CASE(3, 32)
-        EQLB_TILE_CASE(4, 64)
-      }
-#undef EQLB_TILE_CASE
-      cur = nxt;
-      cb = nb;
-      cu = nu;
-    }
-  }
-#else
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int NW = TILE_THREADS / 64;
   int u = wave;
@@ -1861,7 +1754,6 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
   (void)td;
 #endif
 #undef EQLB_TILE_BIN
-#endif
   const int32_t* cells = ta.tile_cells + (int64_t)tile * TC;
   const bool conforming = MODE == 1 && ta.facet_owner != nullptr;
   // flush operands of the broken layout: the old values of flux_hdiv are fetched BEFORE the barrier
