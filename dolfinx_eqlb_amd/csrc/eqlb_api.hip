@@ -175,9 +175,11 @@ int find_stress_groups(const eqlb::DeviceMesh& m, const int8_t* facet_type, cons
 // Recursive coordinate bisection of the cell centroids into chunks of exactly `tc` cells (the last
 // one may be short): compact tiles keep the share of rim patches, which are solved by every tile
 // they touch, small.
+// (centroids relative to the bounding box of the mesh, in single precision: the bisection only compares them,
+// ties go by the cell id, and a 12-byte item moves through the selection passes twice as fast as a 24-byte one)
 struct TileItem
 {
-  double x, y;
+  float x, y;
   int32_t cell;
 };
 
@@ -189,6 +191,90 @@ struct RcbCtx
   std::vector<int64_t> cut;   // [nnodes] epoch in which the node was counted as cut
   int64_t epoch = 0;
 };
+
+static inline bool rcb_less(const TileItem& p, const TileItem& q, int axis)
+{
+  const float u = axis ? p.y : p.x, v = axis ? q.y : q.x;
+  return u < v || (u == v && p.cell < q.cell);
+}
+
+// The same partition as rcb_partition (the key (coordinate, cell id) is a total order, so the two halves are
+// determined as SETS) on the host threads, for the few large segments at the top of the recursion where the
+// subtrees do not yet occupy the cores: histogram of the coordinate -> bucket of the splitting element ->
+// exact splitter inside that bucket -> counting partition through a scratch array.
+static void rcb_partition_parallel(TileItem* a, int64_t n, int64_t nl, int axis, float lo, float hi,
+                                   std::vector<TileItem>& tmp)
+{
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::thread::hardware_concurrency(), n / (1 << 15)));
+  constexpr int NBK = 4096;
+  const float scale = (hi > lo) ? (float)NBK / (hi - lo) : 0.0f;
+  auto bucket = [&](const TileItem& t) {
+    const int b = (int)(((axis ? t.y : t.x) - lo) * scale);
+    return b < 0 ? 0 : (b >= NBK ? NBK - 1 : b);
+  };
+  auto run = [&](auto f) {
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t)
+      th.emplace_back(f, t);
+    f(0);
+    for (auto& x : th)
+      x.join();
+  };
+  std::vector<int64_t> hist((size_t)nt * NBK, 0);
+  run([&](int t) {
+    int64_t* hh = &hist[(size_t)t * NBK];
+    for (int64_t i = n * t / nt; i < n * (t + 1) / nt; ++i)
+      ++hh[bucket(a[i])];
+  });
+  int bs = 0;
+  int64_t before = 0;
+  for (; bs < NBK; ++bs)
+  {
+    int64_t c = 0;
+    for (int t = 0; t < nt; ++t)
+      c += hist[(size_t)t * NBK + bs];
+    if (before + c > nl)
+      break;
+    before += c;
+  }
+  if (bs == NBK) // nl == n: nothing to split
+    return;
+  // the nl-th smallest element lives in bucket bs (buckets are ordered by the coordinate)
+  std::vector<TileItem> cand;
+  for (int64_t i = 0; i < n; ++i)
+    if (bucket(a[i]) == bs)
+      cand.push_back(a[i]);
+  std::nth_element(cand.begin(), cand.begin() + (nl - before), cand.end(),
+                   [axis](const TileItem& p, const TileItem& q) { return rcb_less(p, q, axis); });
+  const TileItem piv = cand[(size_t)(nl - before)];
+  // counting partition: [elements below the splitter | the rest]
+  std::vector<int64_t> cnt((size_t)nt + 1, 0);
+  run([&](int t) {
+    int64_t c = 0;
+    for (int64_t i = n * t / nt; i < n * (t + 1) / nt; ++i)
+      c += rcb_less(a[i], piv, axis) ? 1 : 0;
+    cnt[(size_t)t + 1] = c;
+  });
+  for (int t = 0; t < nt; ++t)
+    cnt[(size_t)t + 1] += cnt[(size_t)t];
+  if ((int64_t)tmp.size() < n)
+    tmp.resize((size_t)n);
+  run([&](int t) {
+    const int64_t b = n * t / nt, e = n * (t + 1) / nt;
+    int64_t l = cnt[(size_t)t], r = nl + (b - cnt[(size_t)t]);
+    for (int64_t i = b; i < e; ++i)
+    {
+      if (rcb_less(a[i], piv, axis))
+        tmp[(size_t)l++] = a[i];
+      else
+        tmp[(size_t)r++] = a[i];
+    }
+  });
+  run([&](int t) {
+    const int64_t b = n * t / nt, e = n * (t + 1) / nt;
+    std::copy(tmp.begin() + b, tmp.begin() + e, a + b);
+  });
+}
 
 static void rcb_partition(TileItem* a, int64_t n, int64_t nl, int axis)
 {
@@ -230,6 +316,7 @@ struct RcbPool
 {
   const int32_t* cell_nodes;
   int32_t nnodes;
+  const uint8_t* stretched = nullptr; // [ncells] 1: longest edge^2 > 6 |det J| (aspect ratio above ~3)
   std::mutex mtx;
   std::vector<std::unique_ptr<RcbCtx>> free_list;
   std::unique_ptr<RcbCtx> acquire()
@@ -258,13 +345,17 @@ void rcb_split(TileItem* a, int64_t n, int64_t ntile, int tc, RcbPool& pool, Rcb
 {
   if (ntile <= 1 || n <= tc)
     return;
-  double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+  float lo[2] = {3e38f, 3e38f}, hi[2] = {-3e38f, -3e38f};
+  int64_t nstretched = 0;
+  const bool last_levels = ntile <= 64;
   for (int64_t i = 0; i < n; ++i)
   {
     lo[0] = std::min(lo[0], a[i].x);
     hi[0] = std::max(hi[0], a[i].x);
     lo[1] = std::min(lo[1], a[i].y);
     hi[1] = std::max(hi[1], a[i].y);
+    if (last_levels && pool.stretched)
+      nstretched += pool.stretched[a[i].cell];
   }
   const int64_t tl = ntile / 2;
   const int64_t nl = std::min<int64_t>(n, tl * tc);
@@ -272,8 +363,11 @@ void rcb_split(TileItem* a, int64_t n, int64_t ntile, int tc, RcbPool& pool, Rcb
   // the last levels decide the shape of the tiles: there the cut is chosen by what it costs - the
   // nodes it separates - not by the extent of the bounding box (which misleads on stretched cells:
   // boundary layers, polar meshes)
+  // (where the cells of the segment are not stretched - fewer than 2 % with an aspect ratio above ~3 - the longer
+  //  side of the bounding box IS the cheaper cut, and the two trial partitions with their node counts, which
+  //  dominated the set-up time of isotropic meshes, are skipped)
   std::unique_ptr<RcbCtx> own;
-  if (ntile <= 64)
+  if (last_levels && nstretched * 50 > n)
   {
     if (!c)
     {
@@ -282,12 +376,18 @@ void rcb_split(TileItem* a, int64_t n, int64_t ntile, int tc, RcbPool& pool, Rcb
     }
     rcb_partition(a, n, nl, axis);
     const int64_t c0 = rcb_cut_nodes(a, n, nl, *c);
+    std::vector<TileItem> first(a, a + n); // the partition along `axis`, in case it wins
     rcb_partition(a, n, nl, 1 - axis);
     const int64_t c1 = rcb_cut_nodes(a, n, nl, *c);
     if (c1 < c0)
       axis = 1 - axis; // already partitioned along it
     else
-      rcb_partition(a, n, nl, axis);
+      std::copy(first.begin(), first.end(), a);
+  }
+  else if (n >= (1 << 18) && depth <= 2) // the top of the tree: few segments, many idle cores
+  {
+    std::vector<TileItem> tmp;
+    rcb_partition_parallel(a, n, nl, axis, lo[axis], hi[axis], tmp);
   }
   else
     rcb_partition(a, n, nl, axis);
@@ -367,18 +467,36 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
   }
   SetupTimer tm;
   std::vector<TileItem> items(nc);
+  std::vector<uint8_t> stretched(nc);
+  // bounding box of the nodes: the centroids are stored relative to it (one scale for both directions)
+  double blo[2] = {1e300, 1e300}, bhi[2] = {-1e300, -1e300};
+  for (int32_t i = 0; i < m.nnodes; ++i)
+    for (int d = 0; d < 2; ++d)
+    {
+      blo[d] = std::min(blo[d], m.h_x[3 * (size_t)i + d]);
+      bhi[d] = std::max(bhi[d], m.h_x[3 * (size_t)i + d]);
+    }
+  const double ext = std::max(bhi[0] - blo[0], bhi[1] - blo[1]);
+  const double inv = (ext > 0.0) ? 1.0 / (3.0 * ext) : 0.0;
   parallel_for(nc, 1 << 16, [&](int64_t c) {
     const int32_t* cn = &m.h_cell_nodes[3 * (size_t)c];
     double cx = 0.0, cy = 0.0;
     for (int j = 0; j < 3; ++j)
     {
-      cx += m.h_x[3 * (size_t)cn[j]];
-      cy += m.h_x[3 * (size_t)cn[j] + 1];
+      cx += m.h_x[3 * (size_t)cn[j]] - blo[0];
+      cy += m.h_x[3 * (size_t)cn[j] + 1] - blo[1];
     }
-    items[c] = {cx, cy, (int32_t)c};
+    items[c] = {(float)(cx * inv), (float)(cy * inv), (int32_t)c};
+    const double* p0 = &m.h_x[3 * (size_t)cn[0]];
+    const double* p1 = &m.h_x[3 * (size_t)cn[1]];
+    const double* p2 = &m.h_x[3 * (size_t)cn[2]];
+    const double e1x = p1[0] - p0[0], e1y = p1[1] - p0[1], e2x = p2[0] - p0[0], e2y = p2[1] - p0[1];
+    const double l2 = std::max(std::max(e1x * e1x + e1y * e1y, e2x * e2x + e2y * e2y),
+                               (e2x - e1x) * (e2x - e1x) + (e2y - e1y) * (e2y - e1y));
+    stretched[c] = l2 > 6.0 * std::fabs(e1x * e2y - e1y * e2x) ? 1 : 0;
   });
   const int32_t ntiles = (nc + TC - 1) / TC;
-  RcbPool pool{m.h_cell_nodes.data(), m.nnodes, {}, {}};
+  RcbPool pool{m.h_cell_nodes.data(), m.nnodes, stretched.data(), {}, {}};
   tm.lap("tiles: centroids");
   rcb_split(items.data(), nc, ntiles, TC, pool, nullptr, 0);
   tm.lap("tiles: bisection");
