@@ -91,6 +91,12 @@ def test_gpu_pipeline_bound(k):
     assert np.sqrt(div2.sum()) < 1e-9 * np.sqrt(np.sum(fh ** 2)) and jump.max() < 1e-9
     eta = estimate(sig2[0], osc2, h)
     assert 1.0 - 1e-10 <= eta / err < 1.6
+    # the oscillation term from the device as well (eqlb_oscillation: exact f at the quadrature points,
+    # div(sigma_eq + G) evaluated exactly): the whole estimator of demo_error_estimation.py:93-120
+    eta_osc2 = cpp.oscillation(dm, k, x, G[None], qp, qw, f_ex(xq[..., 0], xq[..., 1])[None])[0]
+    assert np.allclose(eta_osc2, (h / np.pi) ** 2 * osc2, rtol=1e-8, atol=1e-12 * eta_osc2.max())
+    eta_dev = float(np.sqrt(np.sum(sig2[0] + eta_osc2 + 2 * np.sqrt(sig2[0] * eta_osc2))))
+    assert abs(eta_dev - eta) <= 1e-9 * eta
 
 
 def ev_flux_error2(mesh, k, xb, G):
