@@ -22,6 +22,9 @@
 //     mean-value multiplier is eliminated analytically: lambda = sum R / sum M, gamma_node := 0);
 //   * u_k = -A^-1 (B_k gamma) re-uses the multipliers of the cyclic reduction.
 #include "eqlb_device_common.h"
+#ifndef EQLB_STRESS_RING_BPERM
+#define EQLB_STRESS_RING_BPERM 1 // cyclic neighbours of full patches by ds_bpermute (2 per double) instead of two DPP moves + select per dword: 0.538 -> 0.531 ms
+#endif
 #ifndef EQLB_STRESS_REPCR
 #define EQLB_STRESS_REPCR 0
 #endif
@@ -46,22 +49,32 @@ constexpr int SK = 2, SND = 3, SNQ = 3, SNH = 3, SNRT = 8, SNPK = 6;
 template <int P, bool FULL>
 __device__ __forceinline__ double from_prev(double v, int gbase, int sub, int prevl)
 {
+#if EQLB_STRESS_RING_BPERM
+  if constexpr (FULL)
+    return shfl_d(v, gbase + ((sub + P - 1) & (P - 1)));
+#else
   if constexpr (FULL)
   {
     const double a = dpp_d<0x111>(v), b = dpp_d<0x100 + (P - 1)>(v);
     return (sub == 0) ? b : a;
   }
+#endif
   else
     return shfl_d(v, gbase + prevl);
 }
 template <int P, bool FULL>
 __device__ __forceinline__ double from_next(double v, int gbase, int sub, int nextl)
 {
+#if EQLB_STRESS_RING_BPERM
+  if constexpr (FULL)
+    return shfl_d(v, gbase + ((sub + 1) & (P - 1)));
+#else
   if constexpr (FULL)
   {
     const double a = dpp_d<0x101>(v), b = dpp_d<0x110 + (P - 1)>(v);
     return (sub == P - 1) ? b : a;
   }
+#endif
   else
     return shfl_d(v, gbase + nextl);
 }
