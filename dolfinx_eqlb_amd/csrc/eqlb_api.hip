@@ -448,6 +448,20 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
   // makes the tiles fill whole rounds of the 512 workgroup slots (2 per CU): 1M triangles in 2 045
   // tiles of 489 cells run in 4 rounds, 2 084 tiles of 480 cells leave 36 tiles for a fifth
   int TC = tc_fixed > 0 ? tc_fixed : eqlb::tile_cells_of(h->k);
+  if (tc_fixed > 0)
+  {
+    // fused stress launch (tc_fixed = the largest tile its LDS holds): ONE workgroup per CU, so a partial last
+    // round of the 256 slots costs a full round - fit the tile size to whole rounds as below
+    const int64_t slots = 256, tcmax = tc_fixed;
+    TC = (int)std::min<int64_t>(tcmax, 448);
+    if ((int64_t)nc >= slots * 256)
+    {
+      const int64_t rounds = ((int64_t)nc + slots * tcmax - 1) / (slots * tcmax);
+      TC = (int)(((int64_t)nc + rounds * slots - 1) / (rounds * slots));
+    }
+    if (h->tile_cells_user > 0)
+      TC = (int)std::min<int64_t>(h->tile_cells_user, tcmax);
+  }
   if (tc_fixed <= 0)
   {
     // resident workgroup slots of the chip: two per CU for k <= 2, one for k = 3

@@ -842,10 +842,12 @@ __device__ __forceinline__ int xcd_remap2(int b, int n)
 #define EQLB_STRESS_WAVES 2 // waves per SIMD asked from the register allocator
 #endif
 #ifndef EQLB_STRESS_TILE_CELLS
-#define EQLB_STRESS_TILE_CELLS 448
+#define EQLB_STRESS_TILE_CELLS 524
 #endif
-// cells per tile: 2 rows x 448 x 18 doubles + tables = 139 KB; the body needs the whole register budget of
-// two waves per SIMD, so one 8-wave workgroup per CU is resident anyway and may use its LDS
+// LARGEST tile: 2 rows x 524 x 18 doubles + 11.9 KB of tables = 159.3 KB; the body needs the whole register budget
+// of two waves per SIMD, so one 8-wave workgroup per CU is resident anyway and may use all of its LDS.  The
+// tile builder picks the size below this that fills whole rounds of the 256 workgroup slots (1M triangles:
+// 489 cells = 2 045 tiles = 8 rounds, 0.504 ms; 448 cells = 2 233 tiles = 8.7 rounds cost 0.538 ms)
 constexpr int STRESS_TCMAX = EQLB_STRESS_TILE_CELLS;
 } // namespace
 
