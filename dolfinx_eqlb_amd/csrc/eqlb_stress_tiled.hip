@@ -885,13 +885,12 @@ k_se_stress_tiled(const SeArgs a0, const TileArgs ta, const StressRows rows)
     a.slot_offset = td.slot_start[B];                                                               \
     a.patch_offset = td.patch_start[B];                                                             \
     const int nwb_full = (td.nfull[B] * PP) >> 6;                                                   \
+    /* two loops, not one loop with a branch: the register allocation of the full-patch instance (no spills \
+       on its own) is then not tied to the generic one (same wave-block -> wave assignment) */         \
+    for (; u < nwb_full; u += NW)                                                                   \
+      stress_patch_body<PP, true>(a, rows, lds, (int64_t)u * 64 + lane, sSlots, TC);                \
     for (; u < nwb; u += NW)                                                                        \
-    {                                                                                               \
-      if (u < nwb_full)                                                                             \
-        stress_patch_body<PP, true>(a, rows, lds, (int64_t)u * 64 + lane, sSlots, TC);              \
-      else                                                                                          \
-        stress_patch_body<PP, false>(a, rows, lds, (int64_t)u * 64 + lane, sSlots, TC);             \
-    }                                                                                               \
+      stress_patch_body<PP, false>(a, rows, lds, (int64_t)u * 64 + lane, sSlots, TC);               \
     u -= nwb;                                                                                       \
   }
   EQLB_STRESS_BIN(0, 4)
