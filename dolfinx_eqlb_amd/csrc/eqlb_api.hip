@@ -481,6 +481,20 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
   }
   SetupTimer tm;
   std::vector<TileItem> items(nc);
+  const int32_t ntiles = (nc + TC - 1) / TC;
+  bool cached = false;
+  {
+    std::lock_guard<std::mutex> g(h->mesh->tiling_mutex);
+    auto it = h->mesh->tiling_order.find(TC);
+    if (it != h->mesh->tiling_order.end() && (int32_t)it->second.size() == nc)
+    {
+      for (int32_t p = 0; p < nc; ++p)
+        items[p] = {0.0f, 0.0f, it->second[p]};
+      cached = true;
+    }
+  }
+  if (!cached)
+  {
   std::vector<uint8_t> stretched(nc);
   // bounding box of the nodes: the centroids are stored relative to it (one scale for both directions)
   double blo[2] = {1e300, 1e300}, bhi[2] = {-1e300, -1e300};
@@ -509,7 +523,6 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
                                (e2x - e1x) * (e2x - e1x) + (e2y - e1y) * (e2y - e1y));
     stretched[c] = l2 > 6.0 * std::fabs(e1x * e2y - e1y * e2x) ? 1 : 0;
   });
-  const int32_t ntiles = (nc + TC - 1) / TC;
   RcbPool pool{m.h_cell_nodes.data(), m.nnodes, stretched.data(), {}, {}};
   tm.lap("tiles: centroids");
   rcb_split(items.data(), nc, ntiles, TC, pool, nullptr, 0);
@@ -519,6 +532,12 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
     std::sort(items.begin() + (size_t)t * TC, items.begin() + std::min<size_t>((size_t)(t + 1) * TC, nc),
               [](const TileItem& p, const TileItem& q) { return p.cell < q.cell; });
   });
+  std::vector<int32_t> ord(nc);
+  for (int32_t p = 0; p < nc; ++p)
+    ord[p] = items[p].cell;
+  std::lock_guard<std::mutex> g(h->mesh->tiling_mutex);
+  h->mesh->tiling_order[TC] = std::move(ord);
+  }
   // tiles that own a priority cell (ghost rows a neighbour rank waits for) are numbered first: a
   // first launch over them, the halo exchange, and the launch over the rest then overlap
   std::vector<int32_t> order(ntiles);

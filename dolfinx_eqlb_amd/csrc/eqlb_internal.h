@@ -5,6 +5,8 @@
 
 #include <cstdint>
 #include <string>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/eqlb.h"
@@ -213,6 +215,11 @@ int fill_tables_host(int k, int deg, std::vector<double>& out);
 struct eqlb_mesh
 {
   eqlb::DeviceMesh m;
+  // cells in the order of the tile bisection (sorted by cell id inside every tile), per tile size: the tiling
+  // depends on the mesh alone, so further handles on the mesh (SE + EV, a stress handle ...) and further
+  // eqlb_se_set_boundary calls reuse it
+  std::mutex tiling_mutex;
+  std::map<int, std::vector<int32_t>> tiling_order;
 };
 
 struct eqlb_ev
