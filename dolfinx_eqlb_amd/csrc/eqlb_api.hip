@@ -1919,8 +1919,12 @@ int eqlb_se_estimate_stress(eqlb_mesh_t* mesh, int32_t k, const double* flux_hdi
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_estimate_stress: unknown memory space");
   eqlb::DeviceMesh& m = mesh->m;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (node_asym && !m.node_cells && upload(&m.node_cells, m.h_node_cells.data(), m.h_node_cells.size()))
-    return fail(EQLB_ERR_DEVICE, "eqlb_se_estimate_stress: device allocation failed");
+  if (node_asym)
+  {
+    std::lock_guard<std::mutex> g(mesh->tiling_mutex); // (the mesh-level lock: first use from several threads)
+    if (!m.node_cells && upload(&m.node_cells, m.h_node_cells.data(), m.h_node_cells.size()))
+      return fail(EQLB_ERR_DEVICE, "eqlb_se_estimate_stress: device allocation failed");
+  }
   const size_t nx = (size_t)m.ncells * k * (k + 2);
   int rc;
   if (memspace == EQLB_MEM_DEVICE)
