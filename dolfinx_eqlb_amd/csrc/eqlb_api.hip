@@ -469,9 +469,7 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
     const int64_t slots = (h->k <= 2) ? 512 : 256, tcmax = ev3 ? eqlb::tile_cells_ev_of(h->k) : eqlb::tile_cells_max_of(h->k);
     if (ev3)
       TC = eqlb::tile_cells_ev_of(h->k);
-    // (k = 3, one workgroup per CU: measured, the largest tile the LDS holds wins over the round fit -
-    //  1M triangles 435 cells 0.3445 ms, 440 cells 0.3393 ms)
-    if ((int64_t)nc >= slots * 256 && h->k <= 2)
+    if ((int64_t)nc >= slots * 256)
     {
       const int64_t rounds = ((int64_t)nc + slots * tcmax - 1) / (slots * tcmax);
       TC = (int)(((int64_t)nc + rounds * slots - 1) / (rounds * slots));

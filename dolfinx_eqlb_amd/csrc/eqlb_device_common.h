@@ -166,6 +166,10 @@ struct Sizes
   // constrained-minimisation (EV) mode: HG | WG behind VQ, staged in LDS behind HB
   static constexpr int NHG = HROW, NWG = NCOMBO * NH * ND * 2, NEV = NHG + NWG; // HG padded like a row of H
   static constexpr int OFF_HG = OFF_VQ + NVQT;
+  // RT_3 tiles stage only the combinations WITHOUT the reversal flag of the load tensor (half of WQ: the LDS
+  // decides their tile size); for a reversed minus facet the load follows from Q_rev = Q blockdiag(B, I):
+  // load_h = sum_j B[j][h] load_j for the K unknowns [d | um] (se_patch_body, HALFWQ)
+  static constexpr int NWQH = NWQT / 2, NTAB_HALF = NTAB - NWQT + NWQH;
   // workgroup size: as many waves as fit a 64 KiB LDS budget for the dense tiles (at least one)
   // k = 4 (dense LDS solver): the tables and the patch tiles leave no room for WG, it is read from global memory
   static constexpr int NEV_LDS = (K >= 4) ? NHG : NEV;

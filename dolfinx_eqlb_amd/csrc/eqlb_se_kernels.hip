@@ -155,8 +155,9 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   double* sH = sF + Z::NF;      // [3][ND][NQ]
   double* sD = sH + Z::NHT;     // [3][ND][2][NQ]
   double* sTE = sD + Z::NDT;    // [NCOMBO][3][NTE]
-  double* sWQ = sTE + Z::NTET;  // [NCOMBO][3][NH][NCOL]
-  double* sHB = sWQ + Z::NWQT;                    // [3][3][K][K]
+  constexpr bool HALFWQ = SCATTER == 2 && K == 3; // Sizes::NWQH
+  double* sWQ = sTE + Z::NTET;  // [NCOMBO][3][NH][NCOLS]; HALFWQ: [NCOMBO / 2][3][NH][NCOLS]
+  double* sHB = sWQ + (HALFWQ ? Z::NWQH : Z::NWQT); // [3][3][K][K]
   double* sHG = sHB + Z::NHB;                     // MODE 1: [ND][NQ]
   // MODE 1: [NCOMBO][NH][ND][2]; RT_4: straight from the table buffer in global memory (Sizes::NEV_LDS)
   const double* sWG = (K >= 4) ? a.tables + Z::OFF_HG + Z::NHG : sHG + Z::NHG;
@@ -620,7 +621,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 #pragma unroll
       for (int q = 0; q < NDIV; ++q)
         full[2 * K + q] = sgn * Rq[1 + q];
-      const double* wq = row16<AL>(sWQ + ci * 3 * NH * NCOLS);
+      const double* wq = row16<AL>(sWQ + (HALFWQ ? (ci >> 1) : ci) * 3 * NH * NCOLS);
 #pragma unroll
       for (int h = 0; h < NH; ++h)
       {
@@ -650,7 +651,28 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
           }
         }
         Le[h] = -(g0 * s0 + g1 * s1 + g2 * s2);
-        if constexpr (MODE == 1)
+      }
+      if constexpr (HALFWQ)
+      {
+        // the staged rows are those of the unreversed minus facet: [d | um] rows through B^T where it is reversed
+        double lt[K];
+#pragma unroll
+        for (int h = 0; h < K; ++h)
+        {
+          double t = 0.0;
+#pragma unroll
+          for (int j = h; j < K; ++j)
+            t += bcoef(j, h) * Le[j];
+          lt[h] = t;
+        }
+#pragma unroll
+        for (int h = 0; h < K; ++h)
+          Le[h] = rev_m ? lt[h] : Le[h];
+      }
+      if constexpr (MODE == 1)
+      {
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
           Le[h] += LeG[h];
       }
     }
@@ -1609,12 +1631,12 @@ constexpr int tile_threads_c(int k) { return (k >= 3) ? EQLB_TILE_THREADS_K3 : E
 #define EQLB_TILE_CELLS 480 // 480 cells x 18 packed values + tables: two workgroups per CU (SE and EV)
 #endif
 #ifndef EQLB_TILE_CELLS_K3
-#define EQLB_TILE_CELLS_K3 440 // 440 cells x 36 packed values + 32 KB of tables = 158 KB: one workgroup per CU
+#define EQLB_TILE_CELLS_K3 492 // LARGEST tile: 492 cells x 36 packed values (141.7 KB) + 21.2 KB of tables (half of WQ) of the 160 KB: one workgroup per CU; the tile builder picks the size that fills whole rounds of the 256 slots
                                // (measured at 1M triangles: 256 threads / 160 cells 0.384 ms, 512 / 320 0.366, 512 / 440 0.339)
 #endif
 constexpr int tile_cells_c(int k) { return (k >= 3) ? EQLB_TILE_CELLS_K3 : EQLB_TILE_CELLS; }
 #ifndef EQLB_TILE_CELLS_K3_EV
-#define EQLB_TILE_CELLS_K3_EV 415 // EV mode stages 7 KB more tensors (HG, WG)
+#define EQLB_TILE_CELLS_K3_EV 468 // EV mode stages 7.2 KB more tensors (HG, WG)
 #endif
 // largest tile the LDS budget of two workgroups per CU allows (k <= 2: 490 x 144 B + tensors <= 80 KB)
 constexpr int tile_cells_max_c(int k) { return (k >= 3) ? EQLB_TILE_CELLS_K3 : (EQLB_TILE_CELLS > 490 ? EQLB_TILE_CELLS : 490); }
@@ -1697,13 +1719,27 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
   // bisection tree (neighbours in space are neighbours in index); give every XCD one contiguous
   // range of tiles so that the rim cells two tiles share are read through the same L2
   const int tile = ta.tile_first + xcd_remap(blockIdx.x, ta.ntiles);
-  constexpr int NTABM = Z::NTAB + (MODE ? Z::NEV : 0);
+  constexpr bool HALFWQ = K == 3; // as in se_patch_body
+  constexpr int NTABL = HALFWQ ? Z::NTAB_HALF : Z::NTAB;
+  constexpr int NTABM = NTABL + (MODE ? Z::NEV : 0);
   double* sSlots = lds + NTABM;
-  for (int i = threadIdx.x; i < Z::NTAB; i += TILE_THREADS)
-    lds[i] = a0.tables[Z::NS + i];
+  if constexpr (HALFWQ)
+  {
+    constexpr int NHEAD = Z::NF + Z::NHT + Z::NDT + Z::NTET; // F | H | D | TE
+    constexpr int NCMB = 3 * Z::NH * Z::NCOLS;               // one combination of WQ
+    for (int i = threadIdx.x; i < NHEAD; i += TILE_THREADS)
+      lds[i] = a0.tables[Z::NS + i];
+    for (int i = threadIdx.x; i < Z::NWQH; i += TILE_THREADS) // combinations 0, 2, 4, ...: no reversal
+      lds[NHEAD + i] = a0.tables[Z::NS + NHEAD + (i / NCMB) * 2 * NCMB + (i % NCMB)];
+    for (int i = threadIdx.x; i < Z::NHB; i += TILE_THREADS)
+      lds[NHEAD + Z::NWQH + i] = a0.tables[Z::NS + NHEAD + Z::NWQT + i];
+  }
+  else
+    for (int i = threadIdx.x; i < Z::NTAB; i += TILE_THREADS)
+      lds[i] = a0.tables[Z::NS + i];
   if constexpr (MODE == 1)
     for (int i = threadIdx.x; i < Z::NEV; i += TILE_THREADS)
-      lds[Z::NTAB + i] = a0.tables[Z::OFF_HG + i];
+      lds[NTABL + i] = a0.tables[Z::OFF_HG + i];
   // every packed row of an owned cell is written completely by the patch of its vertex; rows of
   // vertices that this rank does not equilibrate (node mask; flagged per tile) must read as zero in
   // the flush
@@ -1953,7 +1989,7 @@ static int launch_tiled_kd(const SeArgs& a, const TileArgs& t, hipStream_t strea
 {
   using Z = Sizes<K, DEG, 8>;
   const size_t lds_bytes
-      = sizeof(double) * ((size_t)Z::NTAB + (MODE ? (size_t)Z::NEV : 0) + (size_t)t.tc * 3 * (Z::NRT - K));
+      = sizeof(double) * ((size_t)(K == 3 ? Z::NTAB_HALF : Z::NTAB) + (MODE ? (size_t)Z::NEV : 0) + (size_t)t.tc * 3 * (Z::NRT - K));
   if (lds_bytes > 160 * 1024 || t.tc < 1 || t.tc > tile_cells_max_c(K))
     return EQLB_ERR_UNSUPPORTED;
   auto kern = k_se_patch_tiled<K, DEG, MODE>;
