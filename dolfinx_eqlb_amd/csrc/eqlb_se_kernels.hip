@@ -1837,6 +1837,64 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
         xv[it][0] = (xi[it] >= 0) ? x[xi[it]] : 0.0;
     }
   }
+  // conforming layout (hierarchic basis): the owner codes, the DOF numbers and the old values of this thread's
+  // facet / interior entries are fetched BEFORE the barrier as well (three dependent loads otherwise sit
+  // between the barrier and the stores of every tile)
+  constexpr int NIC = K * K - K;
+  constexpr int NFE = (TCMAX * 3 + TILE_THREADS - 1) / TILE_THREADS;
+  constexpr int NIE = (NIC > 0) ? (TCMAX * NIC + TILE_THREADS - 1) / TILE_THREADS : 1;
+  int32_t fcode[NFE];
+  int64_t fdof[NFE];
+  double fold[NFE][K];
+  int64_t idof[NIE];
+  double iold[NIE];
+  const bool conf_plain = conforming && ta.basis_C == nullptr;
+  if (conf_plain)
+  {
+    const double* xc0 = a0.out + (int64_t)a0.rhs_out * ta.ndofs;
+    const int32_t* own0 = ta.facet_owner + (int64_t)tile * TC * 3;
+#pragma unroll
+    for (int it = 0; it < NFE; ++it)
+    {
+      const int e = it * TILE_THREADS + threadIdx.x;
+      fcode[it] = (e < TC * 3) ? own0[e] : -1;
+    }
+#pragma unroll
+    for (int it = 0; it < NFE; ++it)
+    {
+      const int e = it * TILE_THREADS + threadIdx.x;
+      const int cl = e / 3, lf = e - 3 * cl;
+      fdof[it] = -1;
+      if (fcode[it] >= 0) // facet DOFs are numbered consecutively along j (default map) or looked up per j below
+        fdof[it] = ta.cell_dofs ? (int64_t)cells[cl] * NRT + lf * K : (int64_t)(fcode[it] >> 1) * K;
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+      {
+        fold[it][j] = 0.0;
+        if (fcode[it] >= 0 && ta.accumulate)
+          fold[it][j] = ta.cell_dofs ? xc0[ta.cell_dofs[fdof[it] + j]] : xc0[fdof[it] + j];
+      }
+    }
+    if constexpr (NIC > 0)
+    {
+#pragma unroll
+      for (int it = 0; it < NIE; ++it)
+      {
+        const int e = it * TILE_THREADS + threadIdx.x;
+        const int cl = e / NIC, i = e - cl * NIC;
+        const int32_t cell = (e < TC * NIC) ? cells[cl] : -1;
+        idof[it] = -1;
+        iold[it] = 0.0;
+        if (cell >= 0)
+        {
+          idof[it] = ta.cell_dofs ? (int64_t)ta.cell_dofs[(int64_t)cell * NRT + 3 * K + i]
+                                  : (int64_t)ta.nfacets * K + (int64_t)cell * NIC + i;
+          if (ta.accumulate)
+            iold[it] = xc0[idof[it]];
+        }
+      }
+    }
+  }
   __syncthreads();
 
   if (conforming && ta.basis_C != nullptr)
@@ -1902,17 +1960,15 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
   {
     // conforming DOFs (ev/solve_patch.hpp:223-227): facet DOFs by the first cell of the facet,
     // mapped to the global facet frame (T_f = -I / B), interior DOFs by their cell
-    constexpr int NI = K * K - K;
     double* xc = a0.out + (int64_t)a0.rhs_out * ta.ndofs;
-    const int32_t* own = ta.facet_owner + (int64_t)tile * TC * 3;
-    for (int e = threadIdx.x; e < TC * 3; e += TILE_THREADS)
+#pragma unroll
+    for (int it = 0; it < NFE; ++it)
     {
-      const int32_t code = own[e];
-      if (code < 0)
+      if (fcode[it] < 0)
         continue;
+      const int e = it * TILE_THREADS + threadIdx.x;
       const int cl = e / 3, lf = e - 3 * cl;
-      const int32_t cell = cells[cl], fct = code >> 1;
-      const bool rev = (code & 1) != 0;
+      const bool rev = (fcode[it] & 1) != 0;
       double v[K];
 #pragma unroll
       for (int j = 0; j < K; ++j)
@@ -1924,29 +1980,22 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
 #pragma unroll
         for (int i = 0; i < K; ++i)
           g += (rev ? bcoef(j, i) : ((i == j) ? -1.0 : 0.0)) * v[i];
-        const int64_t dof = ta.cell_dofs ? (int64_t)ta.cell_dofs[(int64_t)cell * NRT + lf * K + j]
-                                         : (int64_t)fct * K + j;
-        if (ta.accumulate)
-          xc[dof] += g;
-        else
-          xc[dof] = g;
+        const int64_t dof = ta.cell_dofs ? (int64_t)ta.cell_dofs[fdof[it] + j] : fdof[it] + j;
+        xc[dof] = fold[it][j] + g;
       }
     }
-    if constexpr (NI > 0)
-      for (int e = threadIdx.x; e < TC * NI; e += TILE_THREADS)
+    if constexpr (NIC > 0)
+    {
+#pragma unroll
+      for (int it = 0; it < NIE; ++it)
       {
-        const int cl = e / NI, i = e - cl * NI;
-        const int32_t cell = cells[cl];
-        if (cell < 0)
+        if (idof[it] < 0)
           continue;
-        const int64_t dof = ta.cell_dofs ? (int64_t)ta.cell_dofs[(int64_t)cell * NRT + 3 * K + i]
-                                         : (int64_t)ta.nfacets * K + (int64_t)cell * NI + i;
-        const double v = packed_sum<K, NPK>(sSlots + (int64_t)cl * 3 * NPK, 3 * K + i);
-        if (ta.accumulate)
-          xc[dof] += v;
-        else
-          xc[dof] = v;
+        const int e = it * TILE_THREADS + threadIdx.x;
+        const int cl = e / NIC, i = e - cl * NIC;
+        xc[idof[it]] = iold[it] + packed_sum<K, NPK>(sSlots + (int64_t)cl * 3 * NPK, 3 * K + i);
       }
+    }
     return;
   }
 
