@@ -20,10 +20,28 @@ def build(force: bool = False):
     """Compile the C restatement (gcc) into oracle/_build/."""
     src = os.path.join(_HERE, "eqlb_oracle.c")
     deps = [src, src[:-2] + ".h", src[:-2] + "_ev.c"]
-    if force or not os.path.exists(_LIB_PATH) or \
+    # the library is compiled with -march=native and travels with the repository snapshot: rebuild where the
+    # host CPU is another one than the one it was built on
+    stamp, host = os.path.join(os.path.dirname(_LIB_PATH), "host.txt"), _host_cpu()
+    try:
+        built_on = open(stamp).read()
+    except OSError:
+        built_on = None
+    if force or not os.path.exists(_LIB_PATH) or built_on != host or \
             os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in deps):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+        with open(stamp, "w") as fh:
+            fh.write(host)
     return _LIB_PATH
+
+
+def _host_cpu():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            lines = [ln for ln in fh if ln.startswith(("model name", "flags"))]
+        return "".join(lines[:2])
+    except OSError:
+        return "unknown"
 
 
 class _Mesh(C.Structure):
