@@ -575,7 +575,7 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
   // first -, in order of first appearance; flat storage, 3 TC entries per tile
   constexpr int NB = eqlb::MAX_BINS;
   std::vector<int32_t> tnodes((size_t)ntiles * 3 * TC);
-  std::vector<int32_t> tcount((size_t)ntiles * 2 * NB, 0); // [tile][bin][full, other]
+  std::vector<int32_t> tcount((size_t)ntiles * 3 * NB, 0); // [tile][bin][full, interior, other]
   auto tile_chunks = [&](auto work) {
     const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(std::thread::hardware_concurrency(), ntiles / 32));
     if (nt <= 1)
@@ -594,10 +594,11 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
     for (int64_t t = t0; t < t1; ++t)
     {
       int nseen = 0;
-      int32_t* cnt = &tcount[(size_t)t * 2 * NB];
+      int32_t* cnt = &tcount[(size_t)t * 3 * NB];
       auto key = [&](int32_t nd) {
         const int b_ = node_bin[nd], Pb = eqlb::BIN_P[b_];
-        return 2 * b_ + ((m.h_node_ncells[nd] == Pb && m.h_node_nfcts[nd] == Pb) ? 0 : 1);
+        const bool interior = m.h_node_ncells[nd] == m.h_node_nfcts[nd]; // no boundary facet at the node
+        return 3 * b_ + (interior ? ((m.h_node_ncells[nd] == Pb) ? 0 : 1) : 2);
       };
       for (int q = 0; q < TC; ++q)
       {
@@ -616,8 +617,8 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
           ++cnt[key(nd)];
         }
       }
-      int32_t pos[2 * NB], acc = 0; // stable counting sort by (bin, full first)
-      for (int q = 0; q < 2 * NB; ++q)
+      int32_t pos[3 * NB], acc = 0; // stable counting sort by (bin, full first, then the other interior patches)
+      for (int q = 0; q < 3 * NB; ++q)
       {
         pos[q] = acc;
         acc += cnt[q];
@@ -627,8 +628,9 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
         out[pos[key(seen[i])]++] = seen[i];
       for (int b_ = 0; b_ < NB; ++b_)
       {
-        tiles[t].nfull[b_] = cnt[2 * b_];
-        tiles[t].npatch[b_] = cnt[2 * b_] + cnt[2 * b_ + 1];
+        tiles[t].nfull[b_] = cnt[3 * b_];
+        tiles[t].nint[b_] = cnt[3 * b_] + cnt[3 * b_ + 1];
+        tiles[t].npatch[b_] = cnt[3 * b_] + cnt[3 * b_ + 1] + cnt[3 * b_ + 2];
       }
     }
   });

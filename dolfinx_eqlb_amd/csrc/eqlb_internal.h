@@ -101,6 +101,7 @@ struct TileDesc
   int32_t patch_start[MAX_BINS];
   int32_t npatch[MAX_BINS];
   int32_t nfull[MAX_BINS]; // leading patches of the bin that are interior with exactly P cells
+  int32_t nint[MAX_BINS];  // leading patches that are interior (no boundary facet), nfull of them full
   int32_t zero;            // 1: a vertex of an owned cell is not equilibrated here (node mask): its row
                            // is never written, the LDS slots of the tile are zeroed first
 };

@@ -134,7 +134,7 @@ __device__ __forceinline__ void ldrow16(const double* p, double (&r)[N])
   }
 }
 
-template <int K, int DEG, int P, int SOLVER, int SCATTER, int BLOCK, int MODE = 0, bool FULL = false>
+template <int K, int DEG, int P, int SOLVER, int SCATTER, int BLOCK, int MODE = 0, bool FULL = false, bool INTR = false>
 __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t block_id, double* lds,
                                               const bool tables_staged = false,
                                               const int64_t lane_index = -1, double* tile_slots = nullptr)
@@ -218,6 +218,13 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   if constexpr (FULL)
   {
     n = P;
+    flag0 = (uint8_t)PFLAG_INTERIOR;
+    flag = (uint8_t)0;
+  }
+  // INTR: every patch of the wave-block is interior (any number of cells): no boundary facet, no flux BC -
+  // the boundary branches fold away, the lane masks stay (unstructured meshes: valence 5 - 7 in groups of 8)
+  if constexpr (INTR)
+  {
     flag0 = (uint8_t)PFLAG_INTERIOR;
     flag = (uint8_t)0;
   }
@@ -1755,6 +1762,9 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
 #ifndef EQLB_EXP_FULLONLY
 #define EQLB_EXP_FULLONLY 0
 #endif
+#ifndef EQLB_TILE_INTERIOR
+#define EQLB_TILE_INTERIOR 1
+#endif
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int NW = TILE_THREADS / 64;
   int u = wave;
@@ -1769,10 +1779,15 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
     /* complete wave-blocks of full patches (RT_1: the body is too small for the second instance to pay) */ \
     constexpr bool SPEC = PP <= 8 && K >= 2;                                                        \
     const int nwb_full = SPEC ? ((td.nfull[B] * PP) >> 6) : 0;                                      \
+    /* wave-blocks of interior patches of any size (the patches behind the full ones; K = 2, P = 8, 16) */ \
+    constexpr bool SPECI = EQLB_TILE_INTERIOR && K == 2 && (PP == 8 || PP == 16);                   \
+    const int nwb_int = SPECI ? ((td.nint[B] * PP) >> 6) : 0;                                       \
     for (; u < nwb; u += NW)                                                                        \
     {                                                                                               \
       if (u < nwb_full)                                                                             \
         se_patch_body<K, DEG, PP, EQLB_TILE_SOLVER, 2, 64, MODE, SPEC>(a, 0, lds, true, (int64_t)u * 64 + lane, sSlots); \
+      else if (SPECI && u < nwb_int)                                                                \
+        se_patch_body<K, DEG, PP, EQLB_TILE_SOLVER, 2, 64, MODE, false, SPECI>(a, 0, lds, true, (int64_t)u * 64 + lane, sSlots); \
       else if (!EQLB_EXP_FULLONLY) /* timing experiment: only the full-patch instance */            \
         se_patch_body<K, DEG, PP, EQLB_TILE_SOLVER, 2, 64, MODE>(a, 0, lds, true, (int64_t)u * 64 + lane, sSlots); \
     }                                                                                               \
