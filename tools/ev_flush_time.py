@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from dolfinx_eqlb_amd import cpp, distributed as dd
 from dolfinx_eqlb_amd.synthetic import make_compatible_data

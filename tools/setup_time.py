@@ -1,5 +1,5 @@
 import time, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from dolfinx_eqlb_amd import cpp
 from dolfinx_eqlb_amd import distributed as dd
 part = dd.StripPartition(500, 0, 1)
