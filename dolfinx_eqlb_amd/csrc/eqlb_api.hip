@@ -1408,7 +1408,14 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
         return EQLB_ERR_DEVICE;
       // slots of (cell, vertex) pairs whose node is not equilibrated here (node_mask, other path) stay zero
       HIP_TRY(hipMemset(h->slots, 0, n_slot * 3 * sizeof(double)));
+      h->slots_first_bin = eqlb::MAX_BINS;
     }
+    // The reduction adds ALL slot rows of a cell.  A run over the bins >= first_bin rewrites only their rows: rows
+    // of the lower bins left by an earlier run over more bins (option "scatter" / "solver" changed on this handle)
+    // would be added again on top of what the tiled launch wrote
+    if (h->slots_first_bin < first_bin)
+      HIP_TRY(hipMemsetAsync(h->slots, 0, n_slot * 3 * sizeof(double), stream));
+    h->slots_first_bin = first_bin;
     eqlb::SeArgs as = a;
     if ((h->mode == 1 && h->k <= 3) || (h->fused && h->solver == EQLB_SOLVER_SHUFFLE))
     {

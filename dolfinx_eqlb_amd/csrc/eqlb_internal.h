@@ -275,6 +275,7 @@ struct eqlb_se
   int32_t t_nprio = 0;              // number of priority tiles
   int32_t tile_first = 0, tile_count = -1; // options "tile_first" / "tile_count" (-1: to the end)
   double* slots = nullptr;          // [nrhs][ncells][3][nrt]
+  int slots_first_bin = 0;          // the slot rows of the bins >= this one hold values of the last slot-path run
   int32_t* status = nullptr;
   // staging for host-memory calls
   double *d_flux_dg = nullptr, *d_rhs_dg = nullptr, *d_flux_hdiv = nullptr;

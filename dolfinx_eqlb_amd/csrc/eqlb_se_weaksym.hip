@@ -20,6 +20,11 @@
 namespace eqlb
 {
 
+// relative size (against the largest entry of the Schur system) below which a pivot counts as zero
+#ifndef EQLB_WS_PIVOT_RTOL
+#define EQLB_WS_PIVOT_RTOL 1e-11
+#endif
+
 template <int K, int P>
 struct WsSizes
 {
@@ -459,7 +464,20 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
     r0[DCMAX] = (sub < dim_c) ? Rg[sub] : 0.0;
     r1[DCMAX] = (sub + P < dim_c) ? Rg[sub + P] : 0.0;
     bool free0 = sub < dim_c, free1 = sub + P < dim_c;
-    int prow[DCMAX]; // pivot row of column c
+    // Rank-revealing threshold.  With DIFFERENT boundary types on the two stress rows the Schur matrix can
+    // lose rank beyond the constant mode (tests/stress_rank.py); a null vector z of it has B_k z = 0 for both
+    // rows, so it does not change u_k = -A^-1 B_k gamma, and on a Galerkin stress the system is consistent:
+    // the multiplier of a column without pivot is set to zero where the reference's PartialPivLU
+    // (se/PatchData.hpp:631-637) divides by a rounding-level pivot - same stress, any member of gamma.
+    double cscale = 0.0;
+#pragma unroll
+    for (int j = 0; j < DCMAX; ++j)
+      cscale = fmax(cscale, fmax(fabs(r0[j]), fabs(r1[j])));
+#pragma unroll
+    for (int off = 1; off < P; off <<= 1)
+      cscale = fmax(cscale, __shfl(cscale, gb + (sub ^ off), 64));
+    const double ptol = EQLB_WS_PIVOT_RTOL * cscale;
+    int prow[DCMAX]; // pivot row of column c (-1: no pivot, multiplier 0)
 #pragma unroll
     for (int c = 0; c < DCMAX; ++c)
     {
@@ -485,10 +503,10 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
             br = orow;
           }
         }
-        if (!(bv > 0.0))
+        if (!(bv > ptol))
         {
-          status_local = pvalid ? 1 : status_local;
-          bv = 1.0;
+          prow[c] = -1; // uniform within the group: bv, br are reduced over all lanes
+          continue;
         }
         prow[c] = br;
         const int owner = gb + (br % P);
@@ -517,7 +535,7 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
     for (int c = DCMAX - 1; c >= 0; --c)
     {
       gam[c] = 0.0;
-      if (c < dim_c)
+      if (c < dim_c && prow[c] >= 0)
       {
         const int br = prow[c];
         const bool second = br >= P;
@@ -538,11 +556,20 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
   }
   else if (sub == 0 && pvalid)
   {
+    // serial variant (bins of more than 16 lanes): Gauss-Jordan with row pivoting and the same
+    // rank-revealing threshold; rows are consumed in order, a column without pivot gets multiplier 0
+    double cscale = 0.0;
+    for (int r = 0; r < dim_c; ++r)
+      for (int j = 0; j < dim_c; ++j)
+        cscale = fmax(cscale, fabs(Cg[r * DCMAX + j]));
+    const double ptol = EQLB_WS_PIVOT_RTOL * cscale;
+    int nr = 0; // rows used so far
+    int8_t pcol[DCMAX]; // row that eliminated column c, -1: none
     for (int c = 0; c < dim_c; ++c)
     {
-      int piv = c;
-      double best = fabs(Cg[c * DCMAX + c]);
-      for (int r = c + 1; r < dim_c; ++r)
+      int piv = nr;
+      double best = (nr < dim_c) ? fabs(Cg[nr * DCMAX + c]) : 0.0;
+      for (int r = nr + 1; r < dim_c; ++r)
       {
         const double v = fabs(Cg[r * DCMAX + c]);
         if (v > best)
@@ -551,39 +578,51 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
           piv = r;
         }
       }
-      if (best == 0.0)
+      if (!(best > ptol))
       {
-        status_local = 1;
+        pcol[c] = -1;
         continue;
       }
-      if (piv != c)
+      if (piv != nr)
       {
         for (int j = 0; j < dim_c; ++j)
         {
-          const double t = Cg[c * DCMAX + j];
-          Cg[c * DCMAX + j] = Cg[piv * DCMAX + j];
+          const double t = Cg[nr * DCMAX + j];
+          Cg[nr * DCMAX + j] = Cg[piv * DCMAX + j];
           Cg[piv * DCMAX + j] = t;
         }
-        const double t = Rg[c];
-        Rg[c] = Rg[piv];
+        const double t = Rg[nr];
+        Rg[nr] = Rg[piv];
         Rg[piv] = t;
       }
-      const double ip = 1.0 / Cg[c * DCMAX + c];
-      for (int r = c + 1; r < dim_c; ++r)
+      const double ip = 1.0 / Cg[nr * DCMAX + c];
+      for (int r = nr + 1; r < dim_c; ++r)
       {
         const double f = Cg[r * DCMAX + c] * ip;
         for (int j = c; j < dim_c; ++j)
-          Cg[r * DCMAX + j] -= f * Cg[c * DCMAX + j];
-        Rg[r] -= f * Rg[c];
+          Cg[r * DCMAX + j] -= f * Cg[nr * DCMAX + j];
+        Rg[r] -= f * Rg[nr];
       }
+      pcol[c] = (int8_t)nr;
+      ++nr;
     }
-    for (int r = dim_c - 1; r >= 0; --r)
+    // back substitution over the pivot columns, right to left; gamma goes to Wg first (Rg holds the rows)
+    double* gm = Wg; // free until the u_k step
+    for (int c = dim_c - 1; c >= 0; --c)
     {
+      if (pcol[c] < 0)
+      {
+        gm[c] = 0.0;
+        continue;
+      }
+      const int r = pcol[c];
       double t = Rg[r];
-      for (int j = r + 1; j < dim_c; ++j)
-        t -= Cg[r * DCMAX + j] * Rg[j];
-      Rg[r] = t / Cg[r * DCMAX + r];
+      for (int j = c + 1; j < dim_c; ++j)
+        t -= Cg[r * DCMAX + j] * gm[j];
+      gm[c] = t / Cg[r * DCMAX + c];
     }
+    for (int c = 0; c < dim_c; ++c)
+      Rg[c] = gm[c];
   }
   wave_sync();
 #endif

@@ -6,7 +6,7 @@ projected flux / RHS (DG_{k-1}) and the hat function (P1)
 edges e0:(v1,v2), e1:(v0,v2), e2:(v0,v1) (interior edge points running from the
 low to the high local vertex), then the cell interior.  DOLFINx' default
 gll_warped variant coincides with equispaced for d <= 2 (i.e. RT_k, k <= 3);
-d = 3 is equispaced here.
+d = 3, 4 are equispaced here (d = 4 only as the primal P_4 of the test solvers).
 """
 
 from fractions import Fraction
@@ -29,10 +29,11 @@ def lagrange_nodes(d: int):
             t = Fraction(i, d)
             nodes.append((_VERT[a][0] + t * (_VERT[b][0] - _VERT[a][0]),
                           _VERT[a][1] + t * (_VERT[b][1] - _VERT[a][1])))
-    if d == 3:
-        nodes.append((Fraction(1, 3), Fraction(1, 3)))
-    elif d > 3:
-        raise NotImplementedError("Lagrange degree > 3 not needed (RT_k, k <= 4)")
+    if d > 4:
+        raise NotImplementedError("Lagrange degree > 4 not needed (RT_k, k <= 4)")
+    for j in range(1, d - 1):
+        for i in range(1, d - j):
+            nodes.append((Fraction(i, d), Fraction(j, d)))
     return nodes
 
 

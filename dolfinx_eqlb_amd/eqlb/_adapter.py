@@ -9,6 +9,10 @@ import numpy as np
 def module():
     """The compiled module; raises if it has not been built (no fallback)."""
     try:
+        # _cpp is linked against libeqlb_amd.so, which pulls in the system HIP runtime: map torch's bundled
+        # runtime first (as cpp.lib() does), or a later `import torch` brings a second runtime that sees no device
+        from .. import cpp
+        cpp._bind_torch_hip_runtime()
         from .. import _cpp
     except ImportError as e:  # pragma: no cover - build problem
         raise RuntimeError(

@@ -161,12 +161,39 @@ def check_jump_condition(mesh, k, sigma_eq, flux_dg, degree_dg=None, atol=1e-10)
     return jump_residual(mesh, k, sigma_eq, flux_dg, degree_dg) < atol
 
 
-def boundary_flux_residual(mesh, k, sigma_eq, flux_dg, facets, degree_dg=None):
-    """max |(sigma_eq + G) . n| on the given (flux-BC, homogeneous) boundary facets."""
+def boundary_flux_residual(mesh, k, sigma_eq, flux_dg, facets, degree_dg=None, boundary_values=None):
+    """max |(sigma_eq + G) . n| on the given (flux-BC, homogeneous) boundary facets.
+    boundary_values [ncells * k(k+2)] (the global boundary DOFs BoundaryData holds): max deviation of the
+    facet DOFs of sigma_eq + G from them instead - check_boundary_conditions of the reference
+    (check_eqlb_conditions.py:90-179) in the hierarchic basis, whose facet DOFs are the moments themselves."""
     degree_dg = k - 1 if degree_dg is None else degree_dg
     facets = np.asarray(facets, dtype=np.int64)
     if facets.size == 0:
         return 0.0
+    if boundary_values is not None:
+        J, detJ, K = cell_geometry(mesh)
+        s, w = make_quadrature_interval(2 * k)
+        cells = mesh.facet_cells[mesh.facet_cells_offsets[facets]]
+        lf = np.argmax(mesh.cell_facets[cells] == facets[:, None], axis=1)
+        nrt = k * (k + 2)
+        dg = Lagrange(degree_dg)
+        c = np.asarray(sigma_eq).reshape(mesh.ncells, nrt)
+        G = np.asarray(flux_dg).reshape(mesh.ncells, dg.ndofs, 2)
+        bv = np.asarray(boundary_values).reshape(mesh.ncells, nrt)
+        worst = 0.0
+        for f in range(3):
+            sel = np.nonzero(lf == f)[0]
+            if sel.size == 0:
+                continue
+            cc = cells[sel]
+            psi = dg.tabulate(ert.facet_points(s)[f])[0]
+            Gq = np.einsum("cjd,qj->cqd", G[cc], psi)
+            pb = np.einsum("cXd,cqd->cqX", K[cc], Gq) * detJ[cc][:, None, None]
+            dens = pb @ np.array(ert.FACET_NORMALS[f], dtype=float)
+            for j in range(k):
+                dof = c[cc, f * k + j] + dens @ (w * s ** j)
+                worst = max(worst, float(np.max(np.abs(dof - bv[cc, f * k + j]))))
+        return worst
     t0, _ = _facet_traces(mesh, k, degree_dg, sigma_eq, flux_dg, facets, 0)
     return float(np.max(np.abs(t0)))
 

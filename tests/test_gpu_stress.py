@@ -198,77 +198,61 @@ def test_fused_stress_launch_node_mask_and_accumulation(oracle_mod):
     assert np.array_equal(eq.equilibrate_host(G, f, np.full_like(x1, 3.0)), x1)
 
 
-# the 12 boundary layouts of python/test/unit/test_stressqlb_bcond.py:147-166: per side of the unit square
-# (x = 0, y = 0, x = 1, y = 1) whether stress row 0 / row 1 carries a flux (traction) condition
-BCOND_LAYOUTS = {
-    1: [[True, False], [False, False]], 2: [[False, True], [False, False]], 3: [[False, False], [False, True]],
-    4: [[False, False], [True, False]], 5: [[True, False], [False, True]], 6: [[True, False], [True, False]],
-    7: [[False, True], [False, True]], 8: [[False, True], [True, False]], 9: [[True, False], [True, True]],
-    10: [[False, True], [True, True]], 11: [[True, True], [False, True]], 12: [[True, True], [True, False]],
-}
-
-
-def _bcond_facet_types(mesh, layout):
-    """facet_type [2, nfacets]: sides 1, 2 (x = 0, y = 0) per the layout, sides 3, 4 primal Dirichlet."""
-    ft = np.zeros((2, mesh.nfacets), dtype=np.int8)
-    bf = mesh.boundary_facets()
-    mp = mesh.facet_midpoints()[bf]
-    ft[:, bf] = 1
-    side = [np.abs(mp[:, 0]) < 1e-12, np.abs(mp[:, 1]) < 1e-12]
-    for s in range(2):
-        for r in range(2):
-            if layout[s][r]:
-                ft[r, bf[side[s]]] = 2
-    return ft
-
-
-@pytest.mark.parametrize("id_bc", sorted(BCOND_LAYOUTS))
-@pytest.mark.parametrize("k", [2, 3])
-@pytest.mark.parametrize("n", [2, 5])
-def test_stress_boundary_layouts(oracle_mod, k, id_bc, n):
-    """Stress rows with DIFFERENT boundary types per row (mixed layouts of test_stressqlb_bcond.py): the
-    device path against the oracle on the reference's 2 x 2 crossed square and on a perturbed 5 x 5 one.
-    Where the reference's node order matters (overlapping groups of two-cell corner patches at RT_2 - the
-    reference's own expected failures 8, 10, 12 belong here) the library refuses; the oracle then either
-    refuses too or the case is skipped as 'outside this build'."""
+def test_fused_stress_after_slot_path_on_the_same_handle(oracle_mod):
+    """One handle, scatter 0 (every bin through the slot buffer) and then AUTO (fused tiles + the bins of more
+    than 8 lanes through the slots): the rows the first call left in the slot buffer must not be added again."""
     from dolfinx_eqlb_amd import cpp
-    from dolfinx_eqlb_amd.mesh import create_unit_square
-    from dolfinx_eqlb_amd.synthetic import make_compatible_data
-    mesh = create_unit_square(n, shuffle_seed=None if n == 2 else 4, perturb=0.0 if n == 2 else 0.2)
-    ft = _bcond_facet_types(mesh, BCOND_LAYOUTS[id_bc])
-    rows = [make_compatible_data(mesh, k, ft[r:r + 1], seed=31 + r) for r in range(2)]
-    G = np.stack([r_[0] for r_ in rows])
-    f = np.stack([r_[1] for r_ in rows])
-    eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(mesh), k, 2, reconstruct_stress=True)
-    try:
-        eq.set_boundary(ft)
-    except RuntimeError as e:
-        assert "overlapping groups" in str(e) or "To many patches" in str(e)
-        pytest.skip("order-dependent grouped patches: " + str(e))
-    import stress_rank
-    bad = [nd for nd, _, _ in stress_rank.deficient_nodes(mesh, k, ft)]
-    try:
-        x = eq.equilibrate_host(G, f)
-    except RuntimeError as e:
-        # the device solve reports a singular symmetry system instead of returning numbers
-        assert "not positive definite" in str(e) and bad
-        return
+    from dolfinx_eqlb_amd.mesh import create_disk
+    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_stress_data
+    k = 2
+    mesh = create_disk(12, 3, shuffle_seed=9)
+    ft = np.repeat(facet_types(mesh, None), 2, axis=0)
+    G, f = make_compatible_stress_data(mesh, k, ft)
     ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f, stress=True)
-    # Patches whose two rows have different boundary types can have a rank-deficient symmetry system
-    # (tests/stress_rank.py, independent of the oracle: e.g. the node between a flux-BC and a Dirichlet row on a
-    # straight side, or the right-angled two-cell corner at RT_2).  A Galerkin stress makes it consistent, the
-    # synthetic rows here (force balance only) do not, and a pivoted LU (oracle, reference) and the device solve
-    # then return different members.  Corrections are patch-local, so every cell outside those patches must
-    # agree to rounding.
-    keep = np.ones(mesh.ncells, dtype=bool)
-    for nd in bad:
-        keep[mesh.node_cells[mesh.node_cells_offsets[nd]:mesh.node_cells_offsets[nd + 1]]] = False
-    assert keep.sum() >= mesh.ncells // 4
-    xc, rc = x.reshape(2, mesh.ncells, -1)[:, keep], ref.reshape(2, mesh.ncells, -1)[:, keep]
-    assert np.abs(xc - rc).max() <= 1e-9 * np.abs(rc).max()
-    # row-wise conditions hold whatever the symmetry step does: divergence, jumps, flux BCs
+    eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(mesh), k, 2, reconstruct_stress=True)
+    eq.set_boundary(ft)
+    for scatter in (0, -1, 0, -1):
+        eq.set_option("scatter", scatter)
+        x = eq.equilibrate_host(G, f)
+        assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max(), scatter
+
+
+@pytest.mark.parametrize("id_bc", list(range(1, 13)))
+@pytest.mark.parametrize("k", [2, 3, 4])
+@pytest.mark.parametrize("mesh_name", ["crossed2", "crossed4p"])
+def test_stress_boundary_layouts(mesh_name, k, id_bc):
+    """test_boundary_conditions of python/test/unit/test_stressqlb_bcond.py:147-287 on the device: the 12 layouts
+    with a traction or a displacement condition per side and stress row, k = 2, 3, 4, REAL Galerkin elasticity
+    stresses (fixtures of tests/golden/make_golden_stress_bcond.py: the reference's 2 x 2 crossed square and a
+    perturbed, orientation-shuffled 4 x 4 one).  Asserted on EVERY cell: flux BCs, divergence, jumps, weak
+    symmetry, and the oracle's numbers.  Patches whose two rows have different boundary types can have a
+    rank-deficient (consistent) symmetry system - the device solve returns the same stress as the reference's
+    pivoted LU there (eqlb_se_weaksym.hip: rank-revealing pivot threshold).  Expected to fail weak symmetry:
+    exactly the reference's own set, RT_2 with layouts 8, 10, 12 (:164-165) - there the system of the two-cell
+    corner patch is inconsistent and the numbers are rounding noise over a zero pivot in the reference too."""
+    from cases import BCOND_EXPECTED_FAILS
+    from golden_util import load_bcond
+    from dolfinx_eqlb_amd import cpp
     from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
+    mesh, cases = load_bcond(mesh_name, k)
+    ft, G, f, bv, ref = cases[id_bc]
+    eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(mesh), k, 2, reconstruct_stress=True)
+    eq.set_boundary(ft, boundary_values=bv)
+    x = eq.equilibrate_host(G, f)
+    assert np.isfinite(x).all()
     for r in range(2):
         res, nrm = chk.divergence_residual(mesh, k, x[r], G[r], f[r])
-        assert res <= 1e-9 * nrm
-        assert chk.boundary_flux_residual(mesh, k, x[r], G[r], np.nonzero(ft[r] == 2)[0]) <= 1e-9 * np.abs(x).max()
+        assert res <= 1e-10 * nrm
+        assert chk.check_jump_condition(mesh, k, x[r], G[r], atol=1e-10)
+        fb = np.nonzero(ft[r] == 2)[0]
+        assert chk.boundary_flux_residual(mesh, k, x[r], G[r], fb, boundary_values=bv[r]) <= 1e-10
+    asym = np.abs(asym_moments(mesh, k, x)[1]).max()
+    dev = np.abs(x - ref).max() / np.abs(ref).max()
+    if (k, id_bc) in BCOND_EXPECTED_FAILS:
+        if asym >= 1e-11 or dev > 1e-9:
+            pytest.xfail(f"reference's expected fail (test_stressqlb_bcond.py:164-165): asymmetry {asym:.1e}, "
+                         f"deviation from the oracle {dev:.1e}")
+        return
+    assert asym < 1e-11
+    assert chk.check_weak_symmetry_condition(mesh, k, x)
+    assert dev <= 1e-9
