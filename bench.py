@@ -31,7 +31,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tools")]  # tools/synthetic.py: the synthetic workload
 
 import numpy as np  # noqa: E402
 
@@ -117,7 +117,7 @@ def main():
     # ---- problem setup (not timed, host only): mesh strip of this rank, compatible synthetic data
     from dolfinx_eqlb_amd import distributed as dd
     from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
-    from dolfinx_eqlb_amd.synthetic import make_compatible_data, make_compatible_stress_data
+    from synthetic import make_compatible_data, make_compatible_stress_data
     part = dd.StripPartition(n, rank, world, shuffle_seed=args.shuffle)
     mesh = part.mesh
     ft = part.facet_types()

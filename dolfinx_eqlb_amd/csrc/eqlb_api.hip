@@ -198,6 +198,56 @@ static inline bool rcb_less(const TileItem& p, const TileItem& q, int axis)
   return u < v || (u == v && p.cell < q.cell);
 }
 
+// Host worker threads of the set-up: capped (the tile builder keeps an O(nnodes) stamp per worker: 16 MB each at
+// 4M nodes, on every rank of a node) and exception safe - an exception inside a std::thread would call
+// std::terminate; the first one is kept and re-thrown by join() in the calling thread, where the C entry points
+// turn it into an error code (EQLB_GUARD).
+static int host_workers(int64_t wanted)
+{
+  const int64_t hw = std::max<int64_t>(1, std::min<int64_t>(std::thread::hardware_concurrency(), 32));
+  return (int)std::max<int64_t>(1, std::min<int64_t>(hw, wanted));
+}
+struct Workers
+{
+  std::vector<std::thread> th;
+  std::exception_ptr err;
+  std::mutex mu;
+  template <typename F>
+  void spawn(F f)
+  {
+    th.emplace_back([this, f]() {
+      try
+      {
+        f();
+      }
+      catch (...)
+      {
+        std::lock_guard<std::mutex> g(mu);
+        if (!err)
+          err = std::current_exception();
+      }
+    });
+  }
+  void join()
+  {
+    for (auto& x : th)
+      x.join();
+    th.clear();
+    if (err)
+    {
+      std::exception_ptr e = err;
+      err = nullptr;
+      std::rethrow_exception(e);
+    }
+  }
+  ~Workers()
+  {
+    for (auto& x : th)
+      if (x.joinable())
+        x.join();
+  }
+};
+
 // The same partition as rcb_partition (the key (coordinate, cell id) is a total order, so the two halves are
 // determined as SETS) on the host threads, for the few large segments at the top of the recursion where the
 // subtrees do not yet occupy the cores: histogram of the coordinate -> bucket of the splitting element ->
@@ -205,7 +255,7 @@ static inline bool rcb_less(const TileItem& p, const TileItem& q, int axis)
 static void rcb_partition_parallel(TileItem* a, int64_t n, int64_t nl, int axis, float lo, float hi,
                                    std::vector<TileItem>& tmp)
 {
-  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::thread::hardware_concurrency(), n / (1 << 15)));
+  const int nt = host_workers(n / (1 << 15));
   constexpr int NBK = 4096;
   const float scale = (hi > lo) ? (float)NBK / (hi - lo) : 0.0f;
   auto bucket = [&](const TileItem& t) {
@@ -213,12 +263,11 @@ static void rcb_partition_parallel(TileItem* a, int64_t n, int64_t nl, int axis,
     return b < 0 ? 0 : (b >= NBK ? NBK - 1 : b);
   };
   auto run = [&](auto f) {
-    std::vector<std::thread> th;
+    Workers w;
     for (int t = 1; t < nt; ++t)
-      th.emplace_back(f, t);
+      w.spawn([f, t]() { f(t); });
     f(0);
-    for (auto& x : th)
-      x.join();
+    w.join();
   };
   std::vector<int64_t> hist((size_t)nt * NBK, 0);
   run([&](int t) {
@@ -412,21 +461,20 @@ void rcb_split(TileItem* a, int64_t n, int64_t ntile, int tc, RcbPool& pool, Rcb
 template <typename F>
 void parallel_for(int64_t n, int64_t min_chunk, F f)
 {
-  const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(std::thread::hardware_concurrency(), n / std::max<int64_t>(min_chunk, 1)));
+  const int64_t nt = host_workers(n / std::max<int64_t>(min_chunk, 1));
   if (nt <= 1)
   {
     for (int64_t i = 0; i < n; ++i)
       f(i);
     return;
   }
-  std::vector<std::thread> th;
+  Workers w;
   for (int64_t t = 0; t < nt; ++t)
-    th.emplace_back([=]() {
+    w.spawn([=]() {
       for (int64_t i = n * t / nt; i < n * (t + 1) / nt; ++i)
         f(i);
     });
-  for (auto& x : th)
-    x.join();
+  w.join();
 }
 
 // Tiled SoA of the plain flux equilibration (EQLB_SCATTER_TILED): cells bisected recursively by
@@ -577,17 +625,16 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
   std::vector<int32_t> tnodes((size_t)ntiles * 3 * TC);
   std::vector<int32_t> tcount((size_t)ntiles * 3 * NB, 0); // [tile][bin][full, interior, other]
   auto tile_chunks = [&](auto work) {
-    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(std::thread::hardware_concurrency(), ntiles / 32));
+    const int64_t nt = host_workers(ntiles / 32);
     if (nt <= 1)
     {
       work(0, ntiles);
       return;
     }
-    std::vector<std::thread> th;
+    Workers wk;
     for (int64_t w = 0; w < nt; ++w)
-      th.emplace_back(work, (int64_t)ntiles * w / nt, (int64_t)ntiles * (w + 1) / nt);
-    for (auto& x : th)
-      x.join();
+      wk.spawn([&work, ntiles, w, nt]() { work((int64_t)ntiles * w / nt, (int64_t)ntiles * (w + 1) / nt); });
+    wk.join();
   };
   tile_chunks([&](int64_t t0, int64_t t1) {
     std::vector<int32_t> stamp(m.nnodes, -1), seen(3 * (size_t)TC);
@@ -726,6 +773,13 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
 
 extern "C" {
 
+// Nothing may leave an extern "C" entry point as an exception (a ctypes / cgo / JNI caller would be terminated):
+// function-try-blocks around the entries that allocate on the host or start worker threads.
+#define EQLB_CATCH_ALL                                                                                       \
+  catch (const std::bad_alloc&) { return fail(EQLB_ERR_NO_MEMORY, "host memory exhausted"); }                \
+  catch (const std::exception& e) { return fail(EQLB_ERR_DEVICE, "internal error: %s", e.what()); }         \
+  catch (...) { return fail(EQLB_ERR_DEVICE, "internal error"); }
+
 const char* eqlb_last_error(void) { return g_error.c_str(); }
 
 int eqlb_device_count(void)
@@ -742,6 +796,7 @@ int eqlb_mesh_create(int32_t nnodes, int32_t ncells, int32_t nfacets, const doub
                      const int32_t* facet_cells, const int32_t* node_cells_offsets,
                      const int32_t* node_cells, const int32_t* node_facets_offsets,
                      const int32_t* node_facets, const uint8_t* facet_perm, eqlb_mesh_t** mesh)
+try
 {
   if (!mesh || nnodes <= 0 || ncells <= 0 || nfacets <= 0 || !x || !cell_nodes || !cell_facets
       || !facet_nodes || !facet_cells_offsets || !facet_cells || !node_cells_offsets || !node_cells
@@ -826,6 +881,7 @@ int eqlb_mesh_create(int32_t nnodes, int32_t ncells, int32_t nfacets, const doub
   *mesh = m;
   return EQLB_OK;
 }
+EQLB_CATCH_ALL
 
 void eqlb_mesh_destroy(eqlb_mesh_t* m)
 {
@@ -851,6 +907,7 @@ int32_t eqlb_mesh_max_patch_cells(const eqlb_mesh_t* mesh) { return mesh ? mesh-
 
 int eqlb_se_create(eqlb_mesh_t* mesh, int32_t k, int32_t degree_dg, int32_t nrhs,
                    int32_t reconstruct_stress, int32_t estimate_korn, eqlb_se_t** handle)
+try
 {
   if (!mesh || !handle || nrhs < 1)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "Equilibration: Input sizes does not match");
@@ -897,6 +954,7 @@ int eqlb_se_create(eqlb_mesh_t* mesh, int32_t k, int32_t degree_dg, int32_t nrhs
   *handle = h;
   return EQLB_OK;
 }
+EQLB_CATCH_ALL
 
 void eqlb_se_destroy(eqlb_se_t* h)
 {
@@ -977,6 +1035,7 @@ int eqlb_se_set_option(eqlb_se_t* h, const char* key, int32_t value)
 
 int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* boundary_values,
                          const uint8_t* node_mask)
+try
 {
   if (!h || !facet_type)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_set_boundary: null argument");
@@ -1130,8 +1189,10 @@ int eqlb_se_set_boundary(eqlb_se_t* h, const int8_t* facet_type, const double* b
   h->boundary_set = true;
   return EQLB_OK;
 }
+EQLB_CATCH_ALL
 
 int eqlb_se_kornconst(eqlb_se_t* h, double* cells_kornconst, int32_t memspace, void* stream_)
+try
 {
   if (!h || !cells_kornconst)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "Equilibration: Input sizes does not match");
@@ -1159,10 +1220,12 @@ int eqlb_se_kornconst(eqlb_se_t* h, double* cells_kornconst, int32_t memspace, v
   }
   return EQLB_OK;
 }
+EQLB_CATCH_ALL
 
 int eqlb_se_equilibrate_with_kornconst(eqlb_se_t* h, const double* flux_dg, const double* rhs_dg,
                                        double* flux_hdiv, double* cells_kornconst,
                                        int32_t memspace, void* stream_)
+try
 {
   if (!cells_kornconst)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "Equilibration: Input sizes does not match");
@@ -1171,6 +1234,7 @@ int eqlb_se_equilibrate_with_kornconst(eqlb_se_t* h, const double* flux_dg, cons
     return st;
   return eqlb_se_kornconst(h, cells_kornconst, memspace, stream_);
 }
+EQLB_CATCH_ALL
 
 int64_t eqlb_se_num_patches(const eqlb_se_t* h) { return h ? h->npatch_total : 0; }
 
@@ -1191,17 +1255,20 @@ int eqlb_se_tiling_info(const eqlb_se_t* h, int64_t* ntiles, int64_t* cells_per_
 }
 
 int eqlb_se_set_priority_cells(eqlb_se_t* h, const int32_t* cells, int32_t n)
+try
 {
   if (!h || n < 0 || (n > 0 && !cells))
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_set_priority_cells: invalid argument");
   h->prio_cells.assign(cells, cells + n);
   return EQLB_OK;
 }
+EQLB_CATCH_ALL
 
 int32_t eqlb_se_num_priority_tiles(const eqlb_se_t* h) { return (h && h->boundary_set) ? h->t_nprio : 0; }
 
 int eqlb_se_equilibrate_tiles(eqlb_se_t* h, const double* flux_dg, const double* rhs_dg, double* flux_hdiv,
                               int32_t tile_first, int32_t tile_count, void* stream)
+try
 {
   if (!h || tile_first < 0)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_equilibrate_tiles: invalid argument");
@@ -1213,10 +1280,12 @@ int eqlb_se_equilibrate_tiles(eqlb_se_t* h, const double* flux_dg, const double*
   h->tile_count = c0;
   return st;
 }
+EQLB_CATCH_ALL
 
 int eqlb_se_export_patches(eqlb_se_t* h, int32_t stride, int32_t* ncells, int32_t* cells,
                            int32_t* fcts, int8_t* fcts_local, int8_t* inodes_local,
                            int8_t* reversed)
+try
 {
   if (!h || !ncells || !cells || !fcts || !fcts_local || !inodes_local || !reversed)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_se_export_patches: null argument");
@@ -1286,6 +1355,7 @@ int eqlb_se_export_patches(eqlb_se_t* h, int32_t stride, int32_t* ncells, int32_
   dfree(d_rv);
   return st ? EQLB_ERR_DEVICE : EQLB_OK;
 }
+EQLB_CATCH_ALL
 
 // The sweep on per-right-hand-side arrays: g[r], f[r], x[r] are the blocks of RHS r (host or device).
 static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const double* const* f_in,
@@ -1640,12 +1710,15 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
 
 int eqlb_se_equilibrate_lists(eqlb_se_t* h, const double* const* flux_dg, const double* const* rhs_dg,
                               double* const* flux_hdiv, int32_t memspace, void* stream)
+try
 {
   return equilibrate_lists(h, flux_dg, rhs_dg, flux_hdiv, memspace, stream);
 }
+EQLB_CATCH_ALL
 
 int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_dg,
                         double* flux_hdiv, int32_t memspace, void* stream_)
+try
 {
   if (!h || !flux_dg || !rhs_dg || !flux_hdiv)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "Equilibration: Input sizes does not match");
@@ -1662,6 +1735,7 @@ int eqlb_se_equilibrate(eqlb_se_t* h, const double* flux_dg, const double* rhs_d
   }
   return equilibrate_lists(h, g.data(), f.data(), x.data(), memspace, stream_);
 }
+EQLB_CATCH_ALL
 
 int eqlb_se_check_status(eqlb_se_t* h, void* stream_)
 {
@@ -1712,6 +1786,7 @@ double eqlb_se_last_kernel_ms(const eqlb_se_t* h, int32_t which)
 int eqlb_project_dg(eqlb_mesh_t* mesh, int32_t degree, int32_t bs, int32_t nrhs, int32_t nq,
                     const double* qpoints, const double* qweights, const double* qvalues,
                     double* out, int32_t memspace, void* stream_)
+try
 {
   if (!mesh || !qpoints || !qweights || !qvalues || !out || bs < 1 || nrhs < 1)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "Local solver: Input sizes does not match");
@@ -1756,6 +1831,7 @@ int eqlb_project_dg(eqlb_mesh_t* mesh, int32_t degree, int32_t bs, int32_t nrhs,
   }
   return rc;
 }
+EQLB_CATCH_ALL
 
 int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, double* out,
                              int32_t capacity)
@@ -2007,6 +2083,7 @@ int eqlb_halo_unpack_add(int32_t nrhs, int32_t nlist, int32_t nrt, int64_t ncell
 
 // ---- constrained-minimisation (EV) equilibrator ---------------------------------------------------
 int eqlb_ev_create(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, eqlb_ev_t** handle)
+try
 {
   if (!handle)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_ev_create: null argument");
@@ -2021,6 +2098,7 @@ int eqlb_ev_create(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, eqlb_ev_t** handl
   *handle = h;
   return EQLB_OK;
 }
+EQLB_CATCH_ALL
 
 void eqlb_ev_destroy(eqlb_ev_t* h)
 {
@@ -2062,6 +2140,7 @@ int eqlb_ev_set_option(eqlb_ev_t* h, const char* key, int32_t value)
 }
 
 int eqlb_ev_set_dofmap(eqlb_ev_t* h, const int32_t* cell_dofs, int64_t ndofs)
+try
 {
   if (!h)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_ev_set_dofmap: null argument");
@@ -2085,6 +2164,7 @@ int eqlb_ev_set_dofmap(eqlb_ev_t* h, const int32_t* cell_dofs, int64_t ndofs)
   se->ev_ndofs = ndofs;
   return EQLB_OK;
 }
+EQLB_CATCH_ALL
 
 int eqlb_ev_set_basis_transform(eqlb_ev_t* h, const double* C, const double* R)
 {
@@ -2177,6 +2257,7 @@ int64_t eqlb_ev_num_dofs(const eqlb_ev_t* h) { return h ? h->se->ev_ndofs : 0; }
 
 int eqlb_ev_set_boundary(eqlb_ev_t* h, const int8_t* facet_type, const double* boundary_values,
                          const uint8_t* node_mask)
+try
 {
   if (!h)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_ev_set_boundary: null argument");
@@ -2213,22 +2294,27 @@ int eqlb_ev_set_boundary(eqlb_ev_t* h, const int8_t* facet_type, const double* b
   }
   return EQLB_OK;
 }
+EQLB_CATCH_ALL
 
 int eqlb_ev_equilibrate(eqlb_ev_t* h, const double* flux_dg, const double* rhs_dg,
                         double* flux_hdiv, int32_t memspace, void* stream)
+try
 {
   if (!h)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "Equilibration: Input sizes does not match");
   return eqlb_se_equilibrate(h->se, flux_dg, rhs_dg, flux_hdiv, memspace, stream);
 }
+EQLB_CATCH_ALL
 
 int eqlb_ev_equilibrate_lists(eqlb_ev_t* h, const double* const* flux_dg, const double* const* rhs_dg,
                               double* const* flux_hdiv, int32_t memspace, void* stream)
+try
 {
   if (!h)
     return fail(EQLB_ERR_INVALID_ARGUMENT, "Equilibration: Input sizes does not match");
   return equilibrate_lists(h->se, flux_dg, rhs_dg, flux_hdiv, memspace, stream);
 }
+EQLB_CATCH_ALL
 
 int64_t eqlb_ev_num_patches(const eqlb_ev_t* h) { return h ? h->se->npatch_total : 0; }
 

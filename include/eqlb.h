@@ -32,6 +32,7 @@ extern "C" {
 #define EQLB_ERR_DEVICE (-4)           /* HIP runtime failure / no device */
 #define EQLB_ERR_PATCH_TOO_LARGE (-5)  /* patch with more than 63 cells (one wavefront per patch) */
 #define EQLB_ERR_SINGULAR (-6)         /* patch system not positive definite (incompatible data) */
+#define EQLB_ERR_NO_MEMORY (-7)        /* host allocation failed during set-up */
 
 /* memory space of the data pointers handed to eqlb_se_equilibrate */
 #define EQLB_MEM_HOST 0

@@ -10,11 +10,11 @@ import torch
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")]
 
 from dolfinx_eqlb_amd import distributed as dd  # noqa: E402
 from dolfinx_eqlb_amd.mesh import create_rectangle  # noqa: E402
-from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data  # noqa: E402
+from synthetic import facet_types, make_compatible_data  # noqa: E402
 from oracle import oracle  # noqa: E402
 
 

@@ -3,7 +3,7 @@
 import numpy as np
 
 from dolfinx_eqlb_amd.mesh import create_unit_square
-from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+from synthetic import facet_types, make_compatible_data
 
 
 def neumann_left_top(mp):

@@ -19,13 +19,13 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")]
 
 import galerkin as gk  # noqa: E402
 from golden_util import save_case  # noqa: E402
 from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk  # noqa: E402
 from dolfinx_eqlb_amd.mesh import create_unit_square  # noqa: E402
-from dolfinx_eqlb_amd.synthetic import facet_types  # noqa: E402
+from synthetic import facet_types  # noqa: E402
 from oracle import oracle  # noqa: E402
 
 

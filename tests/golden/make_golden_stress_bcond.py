@@ -21,7 +21,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")]
 
 from cases import BCOND_EXPECTED_FAILS, BCOND_LAYOUTS, BCOND_MESHES, bcond_case  # noqa: E402
 from test_oracle_stress import asym_moments  # noqa: E402

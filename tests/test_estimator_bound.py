@@ -12,7 +12,7 @@ import pytest
 import galerkin as gk
 from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
 from dolfinx_eqlb_amd.mesh import create_unit_square
-from dolfinx_eqlb_amd.synthetic import facet_types
+from synthetic import facet_types
 
 
 def u_ex(x, y):

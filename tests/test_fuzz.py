@@ -8,7 +8,7 @@ from scipy.spatial import Delaunay
 
 from dolfinx_eqlb_amd.eqlb.conforming import conforming_dofmap
 from dolfinx_eqlb_amd.mesh import create_mesh
-from dolfinx_eqlb_amd.synthetic import make_compatible_data
+from synthetic import make_compatible_data
 
 
 def random_case(seed, k, nrhs):
@@ -86,7 +86,7 @@ def test_gpu_random_meshes_stress(oracle_mod, seed, k):
     """Weak symmetry on random meshes with a random flux-BC pattern (the same for both stress rows);
     two-cell boundary nodes between flux-BC facets trigger the grouped patches at k = 2."""
     from dolfinx_eqlb_amd import cpp
-    from dolfinx_eqlb_amd.synthetic import make_compatible_stress_data
+    from synthetic import make_compatible_stress_data
     from test_oracle_stress import asym_moments
     mesh, ft1, _, _ = random_case(100 + seed, k, 1)
     ft = np.repeat(ft1, 2, axis=0)

@@ -51,7 +51,7 @@ def test_smallest_crossed_square(oracle_mod, k, bc):
     from dolfinx_eqlb_amd import cpp
     from dolfinx_eqlb_amd.eqlb.conforming import conforming_dofmap
     from dolfinx_eqlb_amd.mesh import create_unit_square
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    from synthetic import facet_types, make_compatible_data
     mesh = create_unit_square(1, shuffle_seed=3)
     ft = facet_types(mesh, BCS[bc])
     G, f = make_compatible_data(mesh, k, ft, seed=5)

@@ -9,7 +9,7 @@ from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
 from dolfinx_eqlb_amd.eqlb.conforming import (broken_to_conforming, conforming_dofmap,
                                               conforming_to_broken)
 from dolfinx_eqlb_amd.mesh import create_unit_square
-from dolfinx_eqlb_amd.synthetic import boundary_dofs_from_field, facet_types, make_compatible_data
+from synthetic import boundary_dofs_from_field, facet_types, make_compatible_data
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-11
@@ -243,7 +243,7 @@ def test_ev_basis_transform_with_boundary_values(oracle_mod, k):
     from dolfinx_eqlb_amd import cpp
     from dolfinx_eqlb_amd.eqlb.conforming import broken_to_conforming
     from dolfinx_eqlb_amd.mesh import create_unit_square
-    from dolfinx_eqlb_amd.synthetic import boundary_dofs_from_field, facet_types, make_compatible_data
+    from synthetic import boundary_dofs_from_field, facet_types, make_compatible_data
     from cases import BCS
 
     def w(x, y):

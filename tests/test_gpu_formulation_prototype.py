@@ -37,7 +37,7 @@ def test_prototype_ev_inhomogeneous_bc(oracle_mod, k):
     from dolfinx_eqlb_amd.eqlb.conforming import (broken_to_conforming, conforming_dofmap,
                                                   conforming_to_broken)
     from dolfinx_eqlb_amd.mesh import create_unit_square
-    from dolfinx_eqlb_amd.synthetic import (boundary_dofs_from_field, facet_types,
+    from synthetic import (boundary_dofs_from_field, facet_types,
                                             make_compatible_data)
 
     def w(x, y):

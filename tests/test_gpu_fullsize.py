@@ -36,7 +36,7 @@ def cpp():
 @pytest.fixture(scope="module")
 def mesh500():
     from dolfinx_eqlb_amd.mesh import create_unit_square
-    from dolfinx_eqlb_amd.synthetic import facet_types
+    from synthetic import facet_types
     mesh = create_unit_square(500, shuffle_seed=1234)
     assert mesh.ncells == 1_000_000 and mesh.nnodes == 501_001
     return mesh, facet_types(mesh)
@@ -44,7 +44,7 @@ def mesh500():
 
 @pytest.fixture(scope="module")
 def poisson500(mesh500):
-    from dolfinx_eqlb_amd.synthetic import make_compatible_data
+    from synthetic import make_compatible_data
     mesh, ft = mesh500
     G, f = make_compatible_data(mesh, 2, ft)
     return mesh, ft, G, f
@@ -136,7 +136,7 @@ def test_config2_ev_rt2_1m(cpp, oracle_mod, poisson500):
 def test_config3_stress_rt2_1m(cpp, oracle_mod, mesh500):
     """configs[3]: two stress rows + weak symmetry, data balanced in force and moment."""
     from test_oracle_stress import asym_moments
-    from dolfinx_eqlb_amd.synthetic import make_compatible_stress_data
+    from synthetic import make_compatible_stress_data
     mesh, ft1 = mesh500
     k = 2
     ft = np.repeat(ft1, 2, axis=0)
@@ -178,7 +178,7 @@ def test_config4_kernel_rt3_8m_one_gpu(cpp, oracle_mod):
     (eqlb_se_estimate, itself checked against the numpy predicates in tests/test_gpu_estimate.py), the
     numpy predicates on a random sample of cells / facets, sampled patches against the oracle."""
     from dolfinx_eqlb_amd.mesh import create_unit_square
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    from synthetic import facet_types, make_compatible_data
     k, n = 3, 1414
     mesh = create_unit_square(n, shuffle_seed=1234)
     assert mesh.ncells == 7_997_584 and mesh.nnodes == 4_001_621

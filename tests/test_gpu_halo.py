@@ -16,7 +16,7 @@ def test_three_strips_on_one_gpu(oracle_mod, k):
     from dolfinx_eqlb_amd import cpp
     from dolfinx_eqlb_amd import distributed as dd
     from dolfinx_eqlb_amd.mesh import create_rectangle
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    from synthetic import facet_types, make_compatible_data
     world, n = 3, 6
     nrt = k * (k + 2)
     dev = torch.device("cuda", 0)
@@ -75,7 +75,7 @@ def test_device_calls_report_bad_patches_through_check_status(ev):
     import torch
     from dolfinx_eqlb_amd import cpp
     from dolfinx_eqlb_amd.mesh import create_rectangle
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    from synthetic import facet_types, make_compatible_data
     k = 2
     dev = torch.device("cuda", 0)
     mesh = create_rectangle(6, 6)
@@ -117,7 +117,7 @@ def test_two_phase_sweep_with_halo_between(oracle_mod):
     from dolfinx_eqlb_amd import cpp
     from dolfinx_eqlb_amd import distributed as dd
     from dolfinx_eqlb_amd.mesh import create_rectangle
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    from synthetic import facet_types, make_compatible_data
     world, n, k = 3, 24, 2
     nrt = k * (k + 2)
     dev = torch.device("cuda", 0)
@@ -189,7 +189,7 @@ def test_halo_exchange_class_on_device_with_side_stream_transport(oracle_mod, mo
     from dolfinx_eqlb_amd import cpp
     from dolfinx_eqlb_amd import distributed as dd
     from dolfinx_eqlb_amd.mesh import create_rectangle
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    from synthetic import facet_types, make_compatible_data
     world, n, k, nsteps = 3, 24, 2, 3
     nrt = k * (k + 2)
     dev = torch.device("cuda", 0)

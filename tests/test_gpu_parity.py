@@ -69,7 +69,7 @@ def test_canonical_unperturbed_mesh(cpp, oracle_mod, k):
 def test_golden_vectors(cpp):
     from golden_util import load_case
     gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    names = sorted(f for f in os.listdir(gdir) if f.endswith(".npz") and not f.startswith("ev_"))
+    names = sorted(f for f in os.listdir(gdir) if f.endswith(".npz") and not f.startswith(("ev_", "stress_bcond_")))
     assert names
     for name in names:
         mesh, k, ft, G, f, expected = load_case(os.path.join(gdir, name))
@@ -81,7 +81,7 @@ def test_golden_vectors(cpp):
 def test_multirhs_with_different_bcs(cpp, oracle_mod, k):
     from cases import BCS
     from dolfinx_eqlb_amd.mesh import create_unit_square
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    from synthetic import facet_types, make_compatible_data
     mesh = create_unit_square(5, shuffle_seed=3, perturb=0.2)
     names = ["neumann_lt", "dirichlet", "neumann_bottom"]
     fts = [facet_types(mesh, BCS[n])[0] for n in names]
@@ -125,7 +125,7 @@ def test_node_mask_partition_sums_to_full(cpp):
 
 def test_error_conventions(cpp):
     from dolfinx_eqlb_amd.mesh import create_unit_square
-    from dolfinx_eqlb_amd.synthetic import facet_types
+    from synthetic import facet_types
     mesh = create_unit_square(2, diagonal="right")  # corner patches with one cell
     dm = cpp.DeviceMesh(mesh)
     eq = cpp.SemiExplicitEquilibrator(dm, 1, 1)
@@ -159,7 +159,7 @@ def test_benchmark_size_properties(cpp, k, n, solver):
     size-independent properties instead (divergence and jump residuals, linearity,
     oracle agreement on a sample of patches via a node mask)."""
     from dolfinx_eqlb_amd.mesh import create_unit_square
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    from synthetic import facet_types, make_compatible_data
     mesh = create_unit_square(n, shuffle_seed=1234)
     ft = facet_types(mesh)
     G, f = make_compatible_data(mesh, k, ft)
@@ -174,7 +174,7 @@ def test_benchmark_size_properties(cpp, k, n, solver):
 
 def test_sampled_patches_against_oracle_at_scale(cpp, oracle_mod):
     from dolfinx_eqlb_amd.mesh import create_unit_square
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    from synthetic import facet_types, make_compatible_data
     k, n = 2, 200
     mesh = create_unit_square(n, shuffle_seed=1234)
     ft = facet_types(mesh)
@@ -213,7 +213,7 @@ def test_tiled_scatter_is_bitwise_the_slot_path(cpp, oracle_mod, k, bc):
 def test_tiled_scatter_multirhs_and_node_mask(cpp):
     from cases import BCS
     from dolfinx_eqlb_amd.mesh import create_unit_square
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    from synthetic import facet_types, make_compatible_data
     k = 2
     mesh = create_unit_square(12, shuffle_seed=3, perturb=0.2)
     names = ["neumann_lt", "dirichlet", "neumann_bottom"]
@@ -237,7 +237,7 @@ def test_lower_degree_data_is_embedded(cpp, oracle_mod, k, deg):
     mirror embeds it exactly into DG_{k-1}; the oracle works with the lower degree directly."""
     from dolfinx_eqlb_amd.eqlb.FluxEqlbSE import FluxEqlbSE
     from dolfinx_eqlb_amd.mesh import create_unit_square
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    from synthetic import facet_types, make_compatible_data
     mesh = create_unit_square(6, shuffle_seed=8, perturb=0.25)
     ft = facet_types(mesh, None)
     G, f = make_compatible_data(mesh, k, ft, degree_dg=deg)
@@ -257,7 +257,7 @@ def test_geometry_scaling_and_offset(cpp, oracle_mod, scale, shift):
     """Tiny / huge / far-from-origin cells: the Newton-refined reciprocals of the kernels and the
     centroid-based tiling must not depend on the length scale."""
     from dolfinx_eqlb_amd.mesh import create_mesh, create_unit_square
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    from synthetic import facet_types, make_compatible_data
     k = 2
     base = create_unit_square(9, shuffle_seed=21, perturb=0.3)
     mesh = create_mesh(base.x[:, :2] * scale + shift, base.cell_nodes)
@@ -289,7 +289,7 @@ def test_invalid_connectivity_is_refused(cpp):
     """Bad index tables must be caught on the host (they would fault on the device)."""
     import copy
     from dolfinx_eqlb_amd.mesh import create_unit_square
-    from dolfinx_eqlb_amd.synthetic import facet_types
+    from synthetic import facet_types
     mesh = create_unit_square(3)
     bad = copy.copy(mesh)
     bad.cell_nodes = mesh.cell_nodes.copy()
@@ -309,7 +309,7 @@ def test_anisotropic_cells(cpp, oracle_mod, k, aspect):
     """Stretched meshes (cell aspect ratio up to 1000): conditioning of the patch systems grows with
     the aspect ratio; the device path must track the oracle within the conditioning."""
     from dolfinx_eqlb_amd.mesh import create_mesh, create_unit_square
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    from synthetic import facet_types, make_compatible_data
     base = create_unit_square(7, shuffle_seed=13, perturb=0.25)
     xy = base.x[:, :2].copy()
     xy[:, 0] *= aspect
@@ -328,7 +328,7 @@ def test_tiling_is_independent_of_the_cell_aspect_ratio(cpp, aspect):
     so that stretched meshes (boundary layers) get the same share of re-solved rim patches as
     isotropic ones."""
     from dolfinx_eqlb_amd.mesh import create_mesh, create_unit_square
-    from dolfinx_eqlb_amd.synthetic import facet_types
+    from synthetic import facet_types
     base = create_unit_square(120)
     xy = base.x[:, :2].copy()
     xy[:, 0] *= aspect

@@ -39,7 +39,7 @@ def test_stress_high_valence(oracle_mod, k, ns):
     """Weak symmetry on a patch of valence 12 / 24 (lanes-per-patch bins 16 / 32)."""
     from dolfinx_eqlb_amd import cpp
     from dolfinx_eqlb_amd.mesh import create_disk
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_stress_data
+    from synthetic import facet_types, make_compatible_stress_data
     mesh = create_disk(ns, 3, shuffle_seed=9)
     ft = np.repeat(facet_types(mesh, None), 2, axis=0)
     G, f = make_compatible_stress_data(mesh, k, ft)
@@ -55,7 +55,7 @@ def test_stress_grouped_boundary_patches_all_neumann(oracle_mod):
     their adjacent internal patches (se/reconstruction.hpp:170-234)."""
     from dolfinx_eqlb_amd import cpp
     from dolfinx_eqlb_amd.mesh import create_unit_square
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_stress_data
+    from synthetic import facet_types, make_compatible_stress_data
     k = 2
     mesh = create_unit_square(5, shuffle_seed=6, perturb=0.2)
     ft = np.repeat(facet_types(mesh, lambda x: np.ones(len(x), dtype=bool)), 2, axis=0)
@@ -75,7 +75,7 @@ def test_stress_with_inhomogeneous_tractions(oracle_mod, k, bc):
     from cases import BCS
     from dolfinx_eqlb_amd import cpp
     from dolfinx_eqlb_amd.mesh import create_unit_square
-    from dolfinx_eqlb_amd.synthetic import (boundary_dofs_from_field, facet_types,
+    from synthetic import (boundary_dofs_from_field, facet_types,
                                             make_compatible_stress_data)
 
     def w0(x, y):
@@ -107,7 +107,7 @@ def test_stress_pivot_free_solve_on_stretched_perturbed_mesh(oracle_mod, aspect)
     conditioning, also on perturbed, stretched cells with shuffled local vertex order."""
     from dolfinx_eqlb_amd import cpp
     from dolfinx_eqlb_amd.mesh import create_mesh, create_unit_square
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_stress_data
+    from synthetic import facet_types, make_compatible_stress_data
     k = 2
     base = create_unit_square(6, shuffle_seed=21, perturb=0.3)
     xy = base.x[:, :2].copy()
@@ -143,7 +143,7 @@ def test_fused_stress_launch_equals_slot_path_and_oracle(oracle_mod, n, shuffle)
     (k_se_stress_tiled, the default) against the slot path (row sweeps, k_se_weaksym_lean, reduction) and
     the oracle; several tiles with rims at n = 24."""
     from dolfinx_eqlb_amd.mesh import create_unit_square
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_stress_data
+    from synthetic import facet_types, make_compatible_stress_data
     k = 2
     mesh = create_unit_square(n, shuffle_seed=shuffle, perturb=0.25 if shuffle else 0.0)
     ft = np.repeat(facet_types(mesh, None), 2, axis=0)
@@ -154,7 +154,7 @@ def test_fused_stress_launch_equals_slot_path_and_oracle(oracle_mod, n, shuffle)
     assert np.abs(fused - slots).max() <= 1e-11 * np.abs(ref).max()
     assert np.abs(asym_moments(mesh, k, fused)[1]).max() < 1e-11
     # a third right-hand side rides along as a plain flux (rows >= gdim, se/reconstruction.hpp:237-270)
-    from dolfinx_eqlb_amd.synthetic import make_compatible_data
+    from synthetic import make_compatible_data
     G3, f3 = make_compatible_data(mesh, k, ft[:1], seed=99)
     ft3 = np.concatenate([ft, ft[:1]])
     fused3, slots3 = _stress_both_paths(mesh, k, ft3, np.concatenate([G, G3[None]]), np.concatenate([f, f3[None]]))
@@ -170,7 +170,7 @@ def test_fused_stress_launch_with_irregular_valence(oracle_mod, ns):
     the centre patch of valence 12 / 24 has more than 8 facets and goes through the generic kernels, its
     rows are added to what the tiled launch wrote."""
     from dolfinx_eqlb_amd.mesh import create_disk
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_stress_data
+    from synthetic import facet_types, make_compatible_stress_data
     k = 2
     mesh = create_disk(ns, 3, shuffle_seed=9)
     ft = np.repeat(facet_types(mesh, None), 2, axis=0)
@@ -203,7 +203,7 @@ def test_fused_stress_after_slot_path_on_the_same_handle(oracle_mod):
     than 8 lanes through the slots): the rows the first call left in the slot buffer must not be added again."""
     from dolfinx_eqlb_amd import cpp
     from dolfinx_eqlb_amd.mesh import create_disk
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_stress_data
+    from synthetic import facet_types, make_compatible_stress_data
     k = 2
     mesh = create_disk(12, 3, shuffle_seed=9)
     ft = np.repeat(facet_types(mesh, None), 2, axis=0)

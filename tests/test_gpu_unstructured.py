@@ -38,7 +38,7 @@ def delaunay_mesh(npts, seed):
 @pytest.mark.parametrize("k", [1, 2, 3])
 def test_se_on_delaunay_mesh(oracle_mod, k):
     from dolfinx_eqlb_amd import cpp
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    from synthetic import facet_types, make_compatible_data
     mesh = delaunay_mesh(900, seed=k)
     val = np.diff(mesh.node_cells_offsets)
     assert val.max() >= 8 and np.unique(val).size >= 5  # a genuine mix of valences
@@ -56,7 +56,7 @@ def test_se_on_delaunay_mesh(oracle_mod, k):
 def test_ev_and_stress_on_delaunay_mesh(oracle_mod):
     from dolfinx_eqlb_amd import cpp
     from dolfinx_eqlb_amd.eqlb.conforming import conforming_dofmap
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data, make_compatible_stress_data
+    from synthetic import facet_types, make_compatible_data, make_compatible_stress_data
     k = 2
     mesh = delaunay_mesh(700, seed=11)
     ft = facet_types(mesh)

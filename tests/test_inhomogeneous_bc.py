@@ -9,7 +9,7 @@ import kkt_reference as kr
 from cases import BCS
 from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
 from dolfinx_eqlb_amd.mesh import create_unit_square
-from dolfinx_eqlb_amd.synthetic import boundary_dofs_from_field, facet_types, make_compatible_data
+from synthetic import boundary_dofs_from_field, facet_types, make_compatible_data
 
 
 def w_lin(x, y):

@@ -9,7 +9,7 @@ import kkt_reference as kr
 from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
 from dolfinx_eqlb_amd.eqlb.conforming import conforming_dofmap
 from dolfinx_eqlb_amd.mesh import create_disk
-from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+from synthetic import facet_types, make_compatible_data
 
 
 def disk_case(ns, nr, k, neumann=False, seed=7):

@@ -8,7 +8,7 @@ import pytest
 
 from cases import make_case
 from dolfinx_eqlb_amd.mesh import create_mesh, create_unit_square
-from dolfinx_eqlb_amd.synthetic import facet_types
+from synthetic import facet_types
 
 
 def test_oracle_korn_invariances(oracle_mod):

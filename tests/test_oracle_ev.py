@@ -11,7 +11,7 @@ from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
 from dolfinx_eqlb_amd.eqlb.conforming import (broken_to_conforming, conforming_dofmap,
                                               conforming_to_broken)
 from dolfinx_eqlb_amd.mesh import create_unit_square
-from dolfinx_eqlb_amd.synthetic import boundary_dofs_from_field, facet_types, make_compatible_data
+from synthetic import boundary_dofs_from_field, facet_types, make_compatible_data
 
 
 def kkt_sweep(mesh, k, ft, G, f, neumann_flux=None):

@@ -22,7 +22,7 @@ from dolfinx_eqlb_amd.elmtlib import e_raviart_thomas as ert
 from dolfinx_eqlb_amd.elmtlib.lagrange import Lagrange
 from dolfinx_eqlb_amd.elmtlib.quadrature import make_quadrature_triangle
 from dolfinx_eqlb_amd.mesh import create_unit_square
-from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_stress_data
+from synthetic import facet_types, make_compatible_stress_data
 
 
 def asym_moments(mesh, k, sig):

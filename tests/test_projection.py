@@ -9,7 +9,7 @@ import pytest
 from cases import make_case
 from dolfinx_eqlb_amd.elmtlib.lagrange import Lagrange
 from dolfinx_eqlb_amd.elmtlib.quadrature import make_quadrature_triangle
-from dolfinx_eqlb_amd.synthetic import dg_points
+from synthetic import dg_points
 
 
 def _poly(deg, seed):

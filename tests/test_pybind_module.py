@@ -185,7 +185,7 @@ def test_fluxbc_with_a_compiled_boundary_kernel(oracle_mod, k, projection):
     from dolfinx_eqlb_amd import _cpp as c
     from dolfinx_eqlb_amd.eqlb import _adapter as ad
     from dolfinx_eqlb_amd.mesh import create_unit_square
-    from dolfinx_eqlb_amd.synthetic import boundary_dofs_from_field, facet_types, make_compatible_data
+    from synthetic import boundary_dofs_from_field, facet_types, make_compatible_data
     mesh = create_unit_square(6, shuffle_seed=5, perturb=0.3)
     ft = facet_types(mesh, BCS["neumann_lt"])
     w0, scale = np.array([0.8, -0.6]), 1.5

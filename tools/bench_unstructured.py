@@ -17,7 +17,7 @@ def main():
     from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_gpu_unstructured import delaunay_mesh
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    from synthetic import facet_types, make_compatible_data
     k, n = 2, 500000
     mesh = delaunay_mesh(n, seed=1)
     ft = facet_types(mesh)

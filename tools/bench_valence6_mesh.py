@@ -16,7 +16,7 @@ def main():
     from dolfinx_eqlb_amd import cpp
     from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
     from dolfinx_eqlb_amd.mesh import create_disk
-    from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+    from synthetic import facet_types, make_compatible_data
     k, n = 2, 8400
     mesh = create_disk(60, n)
     ft = facet_types(mesh)

@@ -10,7 +10,7 @@ import numpy as np  # noqa: E402
 
 from dolfinx_eqlb_amd import cpp  # noqa: E402
 from dolfinx_eqlb_amd.mesh import create_unit_square  # noqa: E402
-from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data  # noqa: E402
+from synthetic import facet_types, make_compatible_data  # noqa: E402
 
 assert "torch" not in sys.modules
 if len(sys.argv) > 1 and sys.argv[1] == "pybind":

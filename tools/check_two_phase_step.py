@@ -16,7 +16,7 @@ def main():
     import torch
     from dolfinx_eqlb_amd import cpp
     from dolfinx_eqlb_amd import distributed as dd
-    from dolfinx_eqlb_amd.synthetic import make_compatible_data
+    from synthetic import make_compatible_data
     n, k, nrt = 500, 2, 8
     part = dd.StripPartition(n, 0, 2)
     mesh, ft = part.mesh, part.facet_types()

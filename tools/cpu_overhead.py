@@ -15,7 +15,7 @@ def main():
     import torch
     from dolfinx_eqlb_amd import cpp
     from dolfinx_eqlb_amd import distributed as dd
-    from dolfinx_eqlb_amd.synthetic import make_compatible_data
+    from synthetic import make_compatible_data
     n, k = 100, 2
     part = dd.StripPartition(n, 0, 1)
     mesh = part.mesh

@@ -2,7 +2,7 @@ import sys, time, numpy as np
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from dolfinx_eqlb_amd import cpp, distributed as dd
-from dolfinx_eqlb_amd.synthetic import make_compatible_data
+from synthetic import make_compatible_data
 part = dd.StripPartition(500, 0, 1); mesh = part.mesh; ft = part.facet_types()
 k = 2
 G, f = make_compatible_data(mesh, k, ft, seed=1)

@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 import numpy as np
 from dolfinx_eqlb_amd import cpp
 from dolfinx_eqlb_amd import distributed as dd
-from dolfinx_eqlb_amd.synthetic import make_compatible_data
+from synthetic import make_compatible_data
 part = dd.StripPartition(500, 0, 1)
 mesh, ft = part.mesh, part.facet_types()
 G, f = make_compatible_data(mesh, 2, ft)

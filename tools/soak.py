@@ -6,7 +6,7 @@ import numpy as np
 import torch
 from dolfinx_eqlb_amd import cpp
 from dolfinx_eqlb_amd.mesh import create_unit_square
-from dolfinx_eqlb_amd.synthetic import facet_types, make_compatible_data
+from synthetic import facet_types, make_compatible_data
 
 torch.cuda.init()
 mesh = create_unit_square(60, shuffle_seed=1, perturb=0.2)

@@ -1,4 +1,5 @@
-"""Synthetic, Galerkin-compatible input data for the equilibration (no DOLFINx/PETSc here).
+"""TEST / BENCH DATA (not part of the product package): synthetic, Galerkin-compatible input data for the
+equilibration (no DOLFINx/PETSc here); used by tests/, bench.py, tools/ and __graft_entry__.smoke().
 
 The interior patch problems of the semi-explicit equilibration are solvable only if the
 projected flux G and right-hand side f satisfy the hat-function orthogonality
@@ -15,9 +16,9 @@ import numpy as np
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
-from .eqlb.check_eqlb_conditions import cell_geometry
-from .elmtlib.lagrange import Lagrange
-from .elmtlib.quadrature import make_quadrature_triangle
+from dolfinx_eqlb_amd.eqlb.check_eqlb_conditions import cell_geometry
+from dolfinx_eqlb_amd.elmtlib.lagrange import Lagrange
+from dolfinx_eqlb_amd.elmtlib.quadrature import make_quadrature_triangle
 
 
 def dg_points(mesh, degree):
@@ -53,8 +54,8 @@ def boundary_dofs_from_field(mesh, k, ft_row, w):
     """Global boundary DOFs (what BoundaryData interpolates from a FluxBC,
     base/BoundaryData.cpp:414-623): facet DOFs D_{f,j}(w) = int_0^1 (detJ K w)(x_f(s)) . N_f s^j ds
     of the vector field w(x, y) -> (wx, wy) on the flux-BC facets; [ncells * k(k+2)]."""
-    from .elmtlib import e_raviart_thomas as ert
-    from .elmtlib.quadrature import make_quadrature_interval
+    from dolfinx_eqlb_amd.elmtlib import e_raviart_thomas as ert
+    from dolfinx_eqlb_amd.elmtlib.quadrature import make_quadrature_interval
     out = np.zeros(mesh.ncells * k * (k + 2))
     facets, cells, lf, J, detJ, K = _neumann_facet_geometry(mesh, ft_row)
     if facets.size == 0:
@@ -79,8 +80,8 @@ def boundary_dofs_from_field(mesh, k, ft_row, w):
 def neumann_hat_moments(mesh, ft_row, w, weight=None):
     """r_a = int_{Gamma_N} hat_a (w . n_out) [weight(x, y)] ds for all nodes (compatibility of
     Neumann data; with a weight x or y: the moment balance of stress rows)."""
-    from .elmtlib import e_raviart_thomas as ert
-    from .elmtlib.quadrature import make_quadrature_interval
+    from dolfinx_eqlb_amd.elmtlib import e_raviart_thomas as ert
+    from dolfinx_eqlb_amd.elmtlib.quadrature import make_quadrature_interval
     r = np.zeros(mesh.nnodes)
     facets, cells, lf, J, detJ, K = _neumann_facet_geometry(mesh, ft_row)
     if facets.size == 0:

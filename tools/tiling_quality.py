@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 import torch
 from dolfinx_eqlb_amd import cpp
 from dolfinx_eqlb_amd.mesh import create_mesh, create_unit_square
-from dolfinx_eqlb_amd.synthetic import facet_types
+from synthetic import facet_types
 torch.cuda.init()
 base = create_unit_square(250)
 for aspect in (1.0, 30.0, 1000.0):
