@@ -60,6 +60,12 @@ def parse():
     ap.add_argument("--tile-cells", type=int, default=0, help="cells per tile of the tiled launch (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shuffle", type=int, default=None, help="seed for random local vertex order")
+    ap.add_argument("--nrhs", type=int, default=1,
+                    help="right-hand sides equilibrated by one call (plain fluxes; the reference's multi-RHS test "
+                         "uses 4, test_fluxeqlb_multirhs.py:24-186); not the headline")
+    ap.add_argument("--windows", type=int, default=5,
+                    help="the K-step window is repeated this many times; value / ms_per_step are those of the FIRST "
+                         "window (the contract's timed region), ms_per_step_windows reports min / median / max")
     return ap.parse_args()
 
 
@@ -121,7 +127,9 @@ def main():
     part = dd.StripPartition(n, rank, world, shuffle_seed=args.shuffle)
     mesh = part.mesh
     ft = part.facet_types()
-    nrhs = 2 if args.stress else 1
+    nrhs = 2 if args.stress else max(1, args.nrhs)
+    if args.nrhs > 1 and (args.stress or args.ev or world > 1):
+        sys.exit("bench.py: --nrhs > 1 is a one-GPU line of the plain semi-explicit equilibration")
 
     def strip_data(seed):
         """N > 1: ONE global data set - every strip carries the same rows, made compatible on the
@@ -155,12 +163,17 @@ def main():
             G, f = G2.ravel(), f2.ravel()
     elif world > 1:
         G, f = strip_data(20241003)
+    elif nrhs > 1:
+        ft = np.repeat(ft, nrhs, axis=0)
+        rows = [make_compatible_data(mesh, k, ft[:1], seed=20241003 + 17 * r) for r in range(nrhs)]
+        G = np.concatenate([r_[0] for r_ in rows])
+        f = np.concatenate([r_[1] for r_ in rows])
     else:
         G, f = make_compatible_data(mesh, k, ft, seed=20241003)
 
     # the all-cores CPU figure forks worker processes: do it BEFORE this process touches the GPU
     cpu_all = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stress and not args.ev:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stress and not args.ev and nrhs == 1:
         cpu_all = cpu_baseline_all_cores(mesh, k, ft, G, f)
 
     import torch
@@ -273,7 +286,31 @@ def main():
         nrm = float(np.sqrt(rr[0][1] ** 2 + rr[1][1] ** 2))
         checks["weak_symmetry_residual_max"] = chk.weak_symmetry_residual(mesh, k, xr)[0]
     elif world == 1:
-        res, nrm = chk.divergence_residual(mesh, k, x_host, G, f)
+        rr = [chk.divergence_residual(mesh, k, x_host.reshape(nrhs, -1)[r], G.reshape(nrhs, -1)[r],
+                                      f.reshape(nrhs, -1)[r]) for r in range(nrhs)]
+        res = float(np.sqrt(sum(a_ ** 2 for a_, _ in rr)))
+        nrm = float(np.sqrt(sum(b_ ** 2 for _, b_ in rr)))
+    elif args.ev:
+        # across the ranks, conforming output: the reverse halo completes the DOFs on their OWNER; checked are the
+        # owned cells whose DOFs all stay here (the cells along the interface to the next rank gave their facet
+        # DOFs away: n of 4 n^2 cells)
+        import types
+        from dolfinx_eqlb_amd.eqlb.conforming import conforming_dofmap, conforming_to_broken
+        cd, _ = conforming_dofmap(mesh, k)
+        sent = np.zeros(nout, dtype=bool)
+        for d_ in part.conforming_halo(k)[0].values():
+            sent[d_] = True
+        own = np.nonzero(part.cell_owned & ~sent[cd].any(axis=1))[0]
+        xb = conforming_to_broken(mesh, k, x_host.reshape(nrhs, -1)).reshape(nrhs, mesh.ncells, nrt)
+        sub = types.SimpleNamespace(x=mesh.x, cell_nodes=mesh.cell_nodes[own], ncells=own.size)
+        r2 = n2 = 0.0
+        for r in range(nrhs):
+            a_, b_ = chk.divergence_residual(sub, k, xb[r][own].ravel(), np.zeros(own.size * nd * 2),
+                                             f.reshape(nrhs, -1, nd)[r][own].ravel())
+            r2, n2 = r2 + a_ ** 2, n2 + b_ ** 2
+        t = torch.tensor([r2, n2], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        res, nrm = float(np.sqrt(t[0].item())), float(np.sqrt(t[1].item()))
     elif not args.ev:
         # across the ranks: the owned cells hold their own rows + the rows the neighbour computed for them
         import types
@@ -320,6 +357,23 @@ def main():
     else:
         npatch_total = npatch_local
     step_dev_ms = ev0.elapsed_time(ev1) / args.steps  # device time of one step on the launch stream
+    # the same window again (bench hygiene: one 2 ms window sits inside the box-to-box noise): wall clock per
+    # window, bracketed like the first one
+    win_ms = [elapsed / args.steps * 1e3]
+    for _ in range(max(0, args.windows - 1)):
+        torch.cuda.synchronize()
+        barrier()
+        tw0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        tw = time.perf_counter() - tw0
+        if world > 1:
+            t = torch.tensor([tw], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tw = float(t.item())
+        win_ms.append(tw / args.steps * 1e3)
 
     # ---- per-kernel device times.  A step that is ONE kernel launch: the two HIP events that bracket the
     # timed region.  A step of several kernels: the same K steps once more, now with the library's HIP
@@ -338,7 +392,7 @@ def main():
         patch_kernel = None
     bins_ms = None
     if single_kernel:
-        kernels_ms = {patch_kernel: step_dev_ms}
+        kernels_ms = {patch_kernel + (f" x{nrhs} launches" if nrhs > 1 and not args.stress else ""): step_dev_ms}
         timing_method = "two HIP events around the timed region / steps"
     elif two_phase:
         # per-launch event pairs would serialise the two launches of a step against the halo exchange
@@ -395,6 +449,9 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step_windows": {"n": len(win_ms), "min": float(np.min(win_ms)), "median": float(np.median(win_ms)),
+                                "max": float(np.max(win_ms)), "all": [float(w) for w in win_ms],
+                                "note": "the K-step window repeated; value / ms_per_step are the first window's"},
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -420,6 +477,7 @@ def main():
             "kernel": kname,
             "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
             "traffic": pmc.get("traffic"),
+            "traffic_stale": bool(pmc.get("stale", False)),
             "algorithmic_bytes_per_launch": alg_bytes,
             "kernel_ms": kernels_ms[kname],
             "kernel_ms_method": timing_method,
@@ -453,7 +511,8 @@ def main():
     elif rank == 0 and world == 1 and not args.no_cpu_baseline and args.stress:
         out["cpu_baseline"] = cpu_baseline_stress(mesh, k, ft, G.reshape(2, -1), f.reshape(2, -1))
     elif rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(mesh, k, ft, G, f, npatch_local)
+        # (R right-hand sides: the CPU figure is the one-RHS sweep, R times the work per patch on the device side)
+        out["cpu_baseline"] = cpu_baseline(mesh, k, ft[:1], G.reshape(nrhs, -1)[0], f.reshape(nrhs, -1)[0], npatch_local)
         if cpu_all is not None:
             out["cpu_baseline_all_cores"] = cpu_all
     if rank == 0:
@@ -474,7 +533,26 @@ def measured_counters(kernel):
         return {}
     if v is None:
         return {}
-    return v if isinstance(v, dict) else {"traffic": v}
+    if not isinstance(v, dict):
+        return {"traffic": v}
+    # counters of an older build of the kernel are not this build's: instruction counts are dropped, the traffic
+    # figure is kept but marked
+    sha = kernel_source_sha(kernel)
+    if v.get("kernel_sha") and sha and v["kernel_sha"] != sha:
+        return {"traffic": v.get("traffic"), "stale": True,
+                "source": f"{v.get('source')} (taken on an older build of the kernel)"}
+    return v
+
+
+def kernel_source_sha(kernel):
+    """First 16 hex digits of the sha256 of the source file that holds `kernel` (profiles/traffic.json)."""
+    import hashlib
+    fname = "eqlb_stress_tiled.hip" if "stress_tiled" in kernel else "eqlb_se_kernels.hip"
+    try:
+        with open(os.path.join(ROOT, "dolfinx_eqlb_amd", "csrc", fname), "rb") as fh:
+            return hashlib.sha256(fh.read()).hexdigest()[:16]
+    except OSError:
+        return None
 
 
 def eq_solver_name(v):

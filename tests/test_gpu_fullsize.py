@@ -1,5 +1,6 @@
 """Every BASELINE.json configuration at ITS size on the path that ships (library defaults: tiled
-launch for the flux configurations, slots + weak symmetry for the stress), through the C ABI.
+launch for the flux configurations, the fused tiled launch of both rows + weak symmetry for the RT_2 stress),
+through the C ABI.
 
 At these sizes the CPU oracle is too slow for a full comparison, so each case checks
   * the acceptance predicates of the reference's tests (python/test/unit/
