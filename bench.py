@@ -60,6 +60,11 @@ def parse():
     ap.add_argument("--tile-cells", type=int, default=0, help="cells per tile of the tiled launch (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shuffle", type=int, default=None, help="seed for random local vertex order")
+    ap.add_argument("--halo", choices=["rccl", "torch"], default="rccl",
+                    help="N > 1: transport of the reverse halo - rccl: the library's own grouped ncclSend / ncclRecv "
+                         "(eqlb_halo_exchange) on a communicator made through the C ABI; torch: torch.distributed "
+                         "isend / irecv (nccl backend = RCCL).  rccl falls back to torch if the communicator "
+                         "cannot be made on every rank")
     ap.add_argument("--nrhs", type=int, default=1,
                     help="right-hand sides equilibrated by one call (plain fluxes; the reference's multi-RHS test "
                          "uses 4, test_fluxeqlb_multirhs.py:24-186); not the headline")
@@ -237,11 +242,35 @@ def main():
     d_G = torch.from_numpy(G).to(dev)
     d_f = torch.from_numpy(f).to(dev)
     d_x = torch.zeros(nrhs * nout, dtype=torch.float64, device=dev)
+    comm = None
+    if world > 1 and args.halo == "rccl":
+        # a communicator of the library's own (the C++ host's transport, include/eqlb.h: eqlb_halo_exchange): the
+        # unique id travels through the torch.distributed group that the launcher set up
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        ok = 1.0
+        try:
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(cpp.RcclComm.unique_id()), dtype=torch.uint8))
+        except RuntimeError:
+            ok = 0.0
+        dist.broadcast(idt, 0)
+        if ok:
+            try:
+                comm = cpp.RcclComm(idt.cpu().numpy().tobytes(), world, rank)
+            except RuntimeError as e:
+                print(f"[bench rank {rank}] RCCL communicator through the C ABI failed ({e}); torch transport",
+                      file=sys.stderr, flush=True)
+                ok = 0.0
+        flag = torch.tensor([ok], dtype=torch.float64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() < 1.0 and comm is not None:
+            comm.destroy()
+            comm = None
     if world > 1 and args.ev:
         # conforming DOFs of the ghost cells (facet DOFs travel with them) go to their owner
-        halo = dd.HaloExchange(part, 1, dev, nrhs, lists=part.conforming_halo(k), nentries=nout)
+        halo = dd.HaloExchange(part, 1, dev, nrhs, lists=part.conforming_halo(k), nentries=nout, comm=comm)
     else:
-        halo = dd.HaloExchange(part, nrt, dev, nrhs) if world > 1 else None
+        halo = dd.HaloExchange(part, nrt, dev, nrhs, comm=comm) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
 
     pG, pf, px = d_G.data_ptr(), d_f.data_ptr(), d_x.data_ptr()
@@ -375,6 +404,38 @@ def main():
             tw = float(t.item())
         win_ms.append(tw / args.steps * 1e3)
 
+    # ---- the halo exchange alone (pack, transfer, unpack-add; the rows it moves are whatever the last step left)
+    halo_info = None
+    if halo is not None:
+        scratch = torch.zeros_like(d_x)
+        for _ in range(2):
+            halo.reduce(scratch)
+        torch.cuda.synchronize()
+        barrier()
+        th0 = time.perf_counter()
+        for _ in range(args.steps):
+            halo.reduce(scratch)
+        torch.cuda.synchronize()
+        barrier()
+        th = torch.tensor([(time.perf_counter() - th0) / args.steps * 1e3], dtype=torch.float64, device=dev)
+        dist.all_reduce(th, op=dist.ReduceOp.MAX)
+        if args.ev:
+            hs, hr = part.conforming_halo(k)
+            b_s, b_r = 8 * nrhs * sum(len(v) for v in hs.values()), 8 * nrhs * sum(len(v) for v in hr.values())
+        else:
+            b_s, b_r = part.halo_bytes(nrt, nrhs)
+        hb = torch.tensor([float(b_s), float(b_r)], dtype=torch.float64, device=dev)
+        hmax = hb.clone()
+        dist.all_reduce(hmax, op=dist.ReduceOp.MAX)
+        halo_info = {"transport": "eqlb_halo_exchange (RCCL ncclSend/ncclRecv through the C ABI)" if comm is not None
+                     else "torch.distributed isend/irecv (nccl backend = RCCL)",
+                     "rank0_bytes_sent": int(b_s), "rank0_bytes_received": int(b_r),
+                     "max_bytes_sent": int(hmax[0].item()), "max_bytes_received": int(hmax[1].item()),
+                     "halo_only_ms": float(th.item()),
+                     "note": "halo_only_ms = pack + transfer + unpack-add alone, max over ranks, mean of K calls; "
+                             "inside a step it overlaps the sweep of the interior tiles"}
+        del scratch
+
     # ---- per-kernel device times.  A step that is ONE kernel launch: the two HIP events that bracket the
     # timed region.  A step of several kernels: the same K steps once more, now with the library's HIP
     # event pairs around each kernel group on the launch stream (they would put barrier packets between
@@ -497,6 +558,8 @@ def main():
         out["roofline"]["valu_floor_ms"] = floor_ms
         out["roofline"]["valu_frac"] = floor_ms / kernels_ms[kname] if kernels_ms[kname] > 0 else None
         out["roofline"]["valu_source"] = pmc.get("source")
+    if halo_info is not None:
+        out["halo"] = halo_info
     if tiling is not None:
         out["config"]["tiling"] = tiling
     if res is not None:
@@ -519,6 +582,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if comm is not None:
+            comm.destroy()
         dist.destroy_process_group()
 
 

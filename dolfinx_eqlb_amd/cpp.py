@@ -33,6 +33,8 @@ EXPORTED_SYMBOLS = [
     "eqlb_se_set_priority_cells", "eqlb_se_num_priority_tiles", "eqlb_se_equilibrate_tiles",
     "eqlb_se_equilibrate_lists", "eqlb_ev_equilibrate_lists", "eqlb_se_kornconst",
     "eqlb_ev_set_basis_transform", "eqlb_se_estimate_stress", "eqlb_oscillation",
+    "eqlb_halo_exchange", "eqlb_halo_reduce", "eqlb_rccl_get_unique_id", "eqlb_rccl_comm_create",
+    "eqlb_rccl_comm_destroy",
 ]
 
 _lib = None
@@ -461,6 +463,74 @@ def halo_unpack_add(x_ptr, cells_ptr, buf_ptr, nrhs, nlist, nrt, ncells, stream=
     _check(lib().eqlb_halo_unpack_add(C.c_int32(nrhs), C.c_int32(nlist), C.c_int32(nrt),
                                       C.c_int64(ncells), C.c_void_p(cells_ptr), C.c_void_p(x_ptr),
                                       C.c_void_p(buf_ptr), C.c_void_p(stream)))
+
+
+class RcclComm:
+    """An RCCL communicator made through the library (eqlb_rccl_get_unique_id / eqlb_rccl_comm_create): what
+    a host without an RCCL binding of its own uses for eqlb_halo_exchange / eqlb_halo_reduce.  The 128-byte
+    unique id is made on one rank (`RcclComm.unique_id()`) and distributed by the caller."""
+
+    def __init__(self, unique_id: bytes, nranks: int, rank: int):
+        if len(unique_id) != 128:
+            raise RuntimeError("RcclComm: the unique id has 128 bytes")
+        self._h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _check(lib().eqlb_rccl_comm_create(buf, C.c_int32(nranks), C.c_int32(rank), C.byref(self._h)))
+        self.nranks, self.rank = nranks, rank
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(lib().eqlb_rccl_get_unique_id(buf))
+        return buf.raw
+
+    @property
+    def handle(self):
+        return self._h.value
+
+    def destroy(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().eqlb_rccl_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class HaloPlan:
+    """Host-side argument block of eqlb_halo_reduce / eqlb_halo_exchange: peers and, per peer, device index
+    lists and device staging buffers (raw pointers; the caller keeps the memory alive)."""
+
+    def __init__(self, peers, send_idx_ptrs, nsend, send_buf_ptrs, recv_idx_ptrs, nrecv, recv_buf_ptrs):
+        n = len(peers)
+        self.n = n
+        self.peers = (C.c_int32 * n)(*[int(q) for q in peers])
+        self.send_idx = (C.c_void_p * n)(*[C.c_void_p(int(p) or None) for p in send_idx_ptrs])
+        self.recv_idx = (C.c_void_p * n)(*[C.c_void_p(int(p) or None) for p in recv_idx_ptrs])
+        self.send_buf = (C.c_void_p * n)(*[C.c_void_p(int(p) or None) for p in send_buf_ptrs])
+        self.recv_buf = (C.c_void_p * n)(*[C.c_void_p(int(p) or None) for p in recv_buf_ptrs])
+        self.nsend = (C.c_int64 * n)(*[int(v) for v in nsend])
+        self.nrecv = (C.c_int64 * n)(*[int(v) for v in nrecv])
+
+
+def halo_reduce(comm, plan: HaloPlan, x_ptr, nrhs, nrt, nentries, stream=0):
+    """eqlb_halo_reduce: pack (+ clear), grouped RCCL send / recv, unpack-add - one call, asynchronous."""
+    h = comm.handle if isinstance(comm, RcclComm) else comm
+    _check(lib().eqlb_halo_reduce(C.c_void_p(h), C.c_int32(nrhs), C.c_int32(nrt), C.c_int64(nentries),
+                                  C.c_void_p(x_ptr), C.c_int32(plan.n), plan.peers, plan.send_idx, plan.nsend,
+                                  plan.send_buf, plan.recv_idx, plan.nrecv, plan.recv_buf, C.c_void_p(stream)))
+
+
+def halo_exchange(comm, plan: HaloPlan, nrhs, nrt, stream=0):
+    """eqlb_halo_exchange: the grouped send / recv alone (between halo_pack and halo_unpack_add)."""
+    h = comm.handle if isinstance(comm, RcclComm) else comm
+    sc = (C.c_int64 * plan.n)(*[int(v) * nrhs * nrt for v in plan.nsend])
+    rc = (C.c_int64 * plan.n)(*[int(v) * nrhs * nrt for v in plan.nrecv])
+    _check(lib().eqlb_halo_exchange(C.c_void_p(h), C.c_int32(plan.n), plan.peers, plan.send_buf, sc,
+                                    plan.recv_buf, rc, C.c_void_p(stream)))
 
 
 def get_reference_table(k, degree_dg, name):

@@ -47,6 +47,24 @@ int fail(int code, const char* fmt, ...)
   return code;
 }
 
+} // namespace
+namespace eqlb
+{
+// error message + code for the other translation units of the C ABI (eqlb_halo_rccl.hip)
+int set_error(int code, const char* fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+} // namespace eqlb
+namespace
+{
+
 #define HIP_TRY(expr)                                                                             \
   do                                                                                              \
   {                                                                                               \

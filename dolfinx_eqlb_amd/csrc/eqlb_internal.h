@@ -204,6 +204,7 @@ int launch_estimate_stress(const DeviceMesh& m, const int32_t* node_cells, int k
 int launch_oscillation(const DeviceMesh& m, int k, int nrhs, const double* x_eq, const double* flux_dg, int nq,
                        const double* qpoints, const double* qweights, const double* fvalues, const double* korn,
                        double* out, hipStream_t stream);
+int set_error(int code, const char* fmt, ...); // thread-local message of eqlb_last_error + the code back
 void launch_halo_pack(int nrhs, int32_t nlist, int32_t nrt, int64_t ncells, const int64_t* cells, double* x,
                       double* buf, int clear, hipStream_t stream);
 void launch_halo_unpack_add(int nrhs, int32_t nlist, int32_t nrt, int64_t ncells, const int64_t* cells,

@@ -28,6 +28,9 @@
 #ifndef EQLB_STRESS_REPCR
 #define EQLB_STRESS_REPCR 0
 #endif
+#ifndef EQLB_STRESS_REBUILD_B
+#define EQLB_STRESS_REBUILD_B 1
+#endif
 
 namespace eqlb
 {
@@ -591,30 +594,32 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
   // ring point of the facets before / after facet E_sub (cyclic on interior patches)
   const int cm1 = (sub > 0) ? sub - 1 : (interior ? nf - 1 : -1);
   const int cp1 = (sub + 1 < nf) ? sub + 1 : (interior ? 0 : -1);
+  // rows of B_k owned by this lane (from the tensor VQ and J; also re-derived after the Schur solve, see below)
+  auto build_B = [&](const int k, const int ci_, const double ja, const double jb, double (&Br)[3], double& bcn_,
+                     double& Bd_, double& Bdc_) {
+    // Be[h][j]: k = 0: int (Phi_h)_y psi_j, k = 1: -int (Phi_h)_x psi_j; j = patch node / vertex on the minus
+    // facet (local vertex fp) / vertex on the plus facet (local vertex fm)
+    const double* vq = sVQ + ci_ * 2 * NH * 3;
+    double Bl[NH], Bfp[NH], Bfm[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+    {
+      Bl[h] = active ? (ja * vq[h * 3 + ln] + jb * vq[(NH + h) * 3 + ln]) : 0.0;
+      Bfp[h] = active ? (ja * vq[h * 3 + fp] + jb * vq[(NH + h) * 3 + fp]) : 0.0;
+      Bfm[h] = active ? (ja * vq[h * 3 + fm] + jb * vq[(NH + h) * 3 + fm]) : 0.0;
+    }
+    const double p_fp2 = prevv(Bfp[2]), p_fm2 = prevv(Bfm[2]), p_l2 = prevv(Bl[2]), p_fm0 = prevv(Bfm[0]);
+    Br[0] = row_valid ? p_fp2 : 0.0;
+    Br[1] = row_valid ? Bfp[1] + p_fm2 : 0.0;
+    Br[2] = row_valid ? Bfm[1] : 0.0;
+    bcn_ = row_valid ? Bl[1] + p_l2 : 0.0;
+    Bd_ = row_valid ? Bfp[0] + p_fm0 : 0.0;
+    Bdc_ = group_sum_d<P>(Bl[0], gbase, sub);
+  };
 #pragma unroll
   for (int k = 0; k < 2; ++k)
   {
-    {
-      // Be[h][j]: k = 0: int (Phi_h)_y psi_j, k = 1: -int (Phi_h)_x psi_j; j = patch node / vertex on the minus
-      // facet (local vertex fp) / vertex on the plus facet (local vertex fm)
-      const double* vq = sVQ + ci * 2 * NH * 3;
-      const double ja = (k == 0) ? J10 : -J00, jb = (k == 0) ? J11 : -J01;
-      double Bl[NH], Bfp[NH], Bfm[NH];
-#pragma unroll
-      for (int h = 0; h < NH; ++h)
-      {
-        Bl[h] = active ? (ja * vq[h * 3 + ln] + jb * vq[(NH + h) * 3 + ln]) : 0.0;
-        Bfp[h] = active ? (ja * vq[h * 3 + fp] + jb * vq[(NH + h) * 3 + fp]) : 0.0;
-        Bfm[h] = active ? (ja * vq[h * 3 + fm] + jb * vq[(NH + h) * 3 + fm]) : 0.0;
-      }
-      const double p_fp2 = prevv(Bfp[2]), p_fm2 = prevv(Bfm[2]), p_l2 = prevv(Bl[2]), p_fm0 = prevv(Bfm[0]);
-      Brow[k][0] = row_valid ? p_fp2 : 0.0;
-      Brow[k][1] = row_valid ? Bfp[1] + p_fm2 : 0.0;
-      Brow[k][2] = row_valid ? Bfm[1] : 0.0;
-      bcn[k] = row_valid ? Bl[1] + p_l2 : 0.0;
-      Bd[k] = row_valid ? Bfp[0] + p_fm0 : 0.0;
-      Bdc[k] = group_sum_d<P>(Bl[0], gbase, sub);
-    }
+    build_B(k, ci, (k == 0) ? J10 : -J00, (k == 0) ? J11 : -J01, Brow[k], bcn[k], Bd[k], Bdc[k]);
     // columns of B_k through the chain reduction: ring points, and the patch node on boundary patches
     constexpr int NCEN = FULL ? 0 : 1;
     double col[P + NCEN];
@@ -770,6 +775,17 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
     const double g_prev = ring_prev(gam_own);
     const double g_next = ring_next(gam_own);
     double vr[2], vd[2];
+#if EQLB_STRESS_REBUILD_B
+    // B_k is NOT carried across the Schur solve (12 doubles per lane at the point of the highest register
+    // pressure): re-derived from the tensor and J; the opaque copies keep the compiler from merging the two
+    // computations back into held values
+    int ci2 = ci;
+    double j00 = J00, j01 = J01, j10 = J10, j11 = J11;
+    asm volatile("" : "+v"(ci2), "+v"(j00), "+v"(j01), "+v"(j10), "+v"(j11));
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      build_B(k, ci2, (k == 0) ? j10 : -j00, (k == 0) ? j11 : -j01, Brow[k], bcn[k], Bd[k], Bdc[k]);
+#endif
 #pragma unroll
     for (int k = 0; k < 2; ++k)
     {

@@ -99,6 +99,59 @@ class Partition:
         self._cell_owner_l = cell_owner[local]
         self._cell_holders = vo[local]
 
+    @classmethod
+    def from_local(cls, x_local, cell_nodes_local, node_owner_local, cell_owner_local, cell_global, rank: int,
+                   world: int, node_global=None):
+        """The same decomposition from what ONE rank holds - no global mesh anywhere (an 8M-triangle mesh is
+        not replicated on the 8 ranks of a node; a DOLFINx mesh is distributed to begin with):
+
+          x_local [nn, 2], cell_nodes_local [nc, 3]   the rank's cells = every cell with a vertex it owns
+                                                      (own cells + the ghost layer), local node numbering
+          node_owner_local [nn], cell_owner_local [nc] owning rank of every local node / cell
+          cell_global [nc]                             a global cell id: orders the halo lists the same way on
+                                                      both sides of an interface
+          node_global [nn] (optional)                  global node ids (kept for the caller)
+
+        A cell must be owned by the owner of one of its vertices, shared cells must carry the same local vertex
+        order on every rank that holds them (both as in __init__).  The conforming (EV) halo needs facet
+        ownership across ranks and is available from the global constructor only."""
+        self = cls.__new__(cls)
+        node_owner_local = np.asarray(node_owner_local)
+        cell_owner_local = np.asarray(cell_owner_local)
+        cell_global = np.asarray(cell_global, dtype=np.int64)
+        cn = np.asarray(cell_nodes_local)
+        self.rank, self.world = rank, world
+        vo = node_owner_local[cn]
+        if np.any((cell_owner_local[:, None] != vo).all(axis=1)):
+            raise RuntimeError("Partition: a cell must be owned by the owner of one of its vertices")
+        if not (vo == rank).any(axis=1).all():
+            raise RuntimeError("Partition.from_local: every local cell must have a vertex owned by this rank")
+        self.cell_global = cell_global
+        self.node_global = None if node_global is None else np.asarray(node_global)
+        self.mesh = create_mesh(np.asarray(x_local, dtype=np.float64)[:, :2], cn.astype(np.int32))
+        self.cell_owned = cell_owner_local == rank
+        self.ncells_owned = int(self.cell_owned.sum())
+        self.node_mask = None if world == 1 else (node_owner_local == rank).astype(np.uint8)
+        order = np.argsort(cell_global, kind="stable")
+        self.send, self.recv = {}, {}
+        for q in range(world):
+            if q == rank:
+                continue
+            s = order[(cell_owner_local == q)[order]]
+            if s.size:
+                self.send[q] = s.astype(np.int64)
+            r = order[((cell_owner_local == rank) & (vo == q).any(axis=1))[order]]
+            if r.size:
+                self.recv[q] = r.astype(np.int64)
+        self._gmesh_nfacets = None
+        return self
+
+    def halo_bytes(self, width, nrhs=1):
+        """(bytes sent, bytes received) by this rank in one reverse halo of rows of `width` doubles."""
+        ns = sum(len(v) for v in self.send.values())
+        nr = sum(len(v) for v in self.recv.values())
+        return 8 * width * nrhs * ns, 8 * width * nrhs * nr
+
     @property
     def send_cells(self):
         """All ghost cells (priority cells of the two-phase sweep)."""
@@ -222,8 +275,24 @@ class StripPartition:
     def patch_cells_per_bin(self):
         return _patch_cells_per_bin(self.mesh, self.node_mask)
 
+    def halo_bytes(self, width, nrhs=1):
+        """(bytes sent, bytes received) by this rank in one reverse halo of rows of `width` doubles."""
+        return 8 * width * nrhs * len(self.send_cells), 8 * width * nrhs * len(self.recv_cells)
+
     def conforming_halo(self, k):
         return _conforming_halo(self.mesh, k, self.send, self.recv)
+
+
+class _StreamJoin:
+    """Request object of the RCCL transport: wait() orders the current stream behind the transfer stream."""
+
+    def __init__(self, side):
+        self.side = side
+
+    def wait(self):
+        import torch
+        torch.cuda.current_stream().wait_stream(self.side)
+        return True
 
 
 class HaloExchange:
@@ -234,9 +303,15 @@ class HaloExchange:
     (send, recv) dicts of index arrays per peer with `nentries` = number of rows of the vector
     (EV: the conforming DOF lists of `part.conforming_halo(k)`)."""
 
-    def __init__(self, part, width: int, device, nrhs: int = 1, lists=None, nentries=None):
+    def __init__(self, part, width: int, device, nrhs: int = 1, lists=None, nentries=None, comm=None):
+        """comm: None - transport = torch.distributed point-to-point (isend / irecv; nccl backend = RCCL, or
+        gloo on CPU tensors); a cpp.RcclComm (or raw ncclComm_t) - transport = the library's own grouped
+        ncclSend / ncclRecv (eqlb_halo_reduce / eqlb_halo_exchange), device tensors only."""
         import torch
         self.part, self.nrt, self.nrhs = part, width, nrhs
+        self.comm = comm
+        self._plan = None
+        self._side = None
         self.rank = part.rank
         send, recv = (part.send, part.recv) if lists is None else lists
         self.nentries = part.mesh.ncells if nentries is None else int(nentries)
@@ -269,6 +344,23 @@ class HaloExchange:
         xv = x.view(self.nrhs, self.nentries, self.nrt)
         on_gpu = x.is_cuda
         stream = torch.cuda.current_stream().cuda_stream if on_gpu else 0
+        if self.comm is not None:
+            # the library's transport (eqlb_halo_exchange): pack kernels and the grouped ncclSend / ncclRecv go to
+            # a SIDE stream that waits for what the current stream holds now (the sweep of the tiles that own the
+            # ghost rows); launches enqueued on the current stream after this call overlap the transfer,
+            # finish() makes the current stream wait for the side stream before it unpacks
+            from . import cpp
+            if not on_gpu:
+                raise RuntimeError("HaloExchange: the RCCL transport needs device tensors")
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=x.device)
+            self._side.wait_stream(torch.cuda.current_stream())
+            side = self._side.cuda_stream
+            for q, idx in self.send_idx.items():
+                cpp.halo_pack(x.data_ptr(), idx.data_ptr(), self.send_buf[q].data_ptr(), self.nrhs, idx.numel(),
+                              self.nrt, self.nentries, True, side)
+            cpp.halo_exchange(self.comm, self._rccl_plan(), self.nrhs, self.nrt, side)
+            return [_StreamJoin(self._side)]
         for q, idx in self.send_idx.items():
             buf = self.send_buf[q]
             if on_gpu:
@@ -287,6 +379,27 @@ class HaloExchange:
                     ops.append(dist.P2POp(dist.irecv, self.recv_buf[q], q))
             self._ops = ops
         return dist.batch_isend_irecv(self._ops) if self._ops else []
+
+    def _rccl_plan(self):
+        if self._plan is None:
+            from . import cpp
+            z = lambda d, q: d[q].data_ptr() if q in d else 0  # noqa: E731
+            n = lambda d, q: d[q].numel() if q in d else 0  # noqa: E731
+            self._plan = cpp.HaloPlan(self.peers, [z(self.send_idx, q) for q in self.peers],
+                                      [n(self.send_idx, q) for q in self.peers],
+                                      [z(self.send_buf, q) for q in self.peers],
+                                      [z(self.recv_idx, q) for q in self.peers],
+                                      [n(self.recv_idx, q) for q in self.peers],
+                                      [z(self.recv_buf, q) for q in self.peers])
+        return self._plan
+
+    def reduce_rccl(self, x):
+        """The whole reduction in ONE library call (eqlb_halo_reduce) on the current stream."""
+        import torch
+        from . import cpp
+        cpp.halo_reduce(self.comm, self._rccl_plan(), x.data_ptr(), self.nrhs, self.nrt, self.nentries,
+                        torch.cuda.current_stream().cuda_stream)
+        return x
 
     def finish(self, x, reqs):
         """Second half: wait for the transfer (the current stream waits, not the host) and add the

@@ -306,11 +306,39 @@ int eqlb_oscillation(eqlb_mesh_t* mesh, int32_t k, int32_t nrhs, const double* f
  *   eqlb_halo_pack        buf[r][i][:] = x[r][cells[i]][:]  (i < nlist), rows cleared if clear != 0
  *   eqlb_halo_unpack_add  x[r][cells[i]][:] += buf[r][i][:]
  * x [nrhs][ncells][nrt], cells [nlist] int64, buf [nrhs][nlist][nrt]; asynchronous on `stream`.  The
- * transport between the two calls is the caller's (RCCL send/recv in dolfinx_eqlb_amd/distributed.py). */
+ * transport between the two calls: eqlb_halo_exchange below, or the caller's own (torch.distributed send / recv in
+ * dolfinx_eqlb_amd/distributed.py). */
 int eqlb_halo_pack(int32_t nrhs, int32_t nlist, int32_t nrt, int64_t ncells, const int64_t* cells,
                    double* x, double* buf, int32_t clear, void* stream);
 int eqlb_halo_unpack_add(int32_t nrhs, int32_t nlist, int32_t nrt, int64_t ncells, const int64_t* cells,
                          double* x, const double* buf, void* stream);
+
+/* The transport of the reverse halo in the C++ host itself ("ncclGroupStart; ncclSend / ncclRecv per
+ * neighbour; ncclGroupEnd" - new design, the reference's node loop cpp/dolfinx_eqlb/se/reconstruction.hpp:90 has
+ * no counterpart): grouped point-to-point sends / receives over RCCL (xGMI) on the CALLER's communicator
+ * (`comm` = ncclComm_t) and stream.  RCCL is resolved at run time - first among the libraries the process has
+ * already loaded (the caller's own RCCL), then librccl.so of the ROCm installation; EQLB_ERR_UNSUPPORTED if
+ * there is none.
+ *   eqlb_halo_exchange  peers [npeers] ranks; send_buf[i] / recv_buf[i] DEVICE buffers of send_count[i] /
+ *                       recv_count[i] doubles (0 = nothing in that direction); one ncclGroup for all of them.
+ *   eqlb_halo_reduce    the whole reduction in one call: eqlb_halo_pack (with clear) of the rows send_idx[i]
+ *                       [nsend[i]] of x [nrhs][nentries][nrt] into send_buf[i], the grouped exchange,
+ *                       eqlb_halo_unpack_add of recv_buf[i] onto the rows recv_idx[i] [nrecv[i]]; the index
+ *                       lists are DEVICE arrays (int64), the arrays of pointers / counts HOST arrays; buffers
+ *                       of nrhs * n * nrt doubles.  Asynchronous on `stream`.
+ * Communicator helpers for hosts that do not link RCCL themselves (id128 = ncclUniqueId, 128 bytes, made on one
+ * rank and distributed by the caller - MPI_Bcast where DOLFINx runs):
+ *   eqlb_rccl_get_unique_id, eqlb_rccl_comm_create (ncclCommInitRank), eqlb_rccl_comm_destroy. */
+int eqlb_halo_exchange(void* comm, int32_t npeers, const int32_t* peers, const double* const* send_buf,
+                       const int64_t* send_count, double* const* recv_buf, const int64_t* recv_count,
+                       void* stream);
+int eqlb_halo_reduce(void* comm, int32_t nrhs, int32_t nrt, int64_t nentries, double* x, int32_t npeers,
+                     const int32_t* peers, const int64_t* const* send_idx, const int64_t* nsend,
+                     double* const* send_buf, const int64_t* const* recv_idx, const int64_t* nrecv,
+                     double* const* recv_buf, void* stream);
+int eqlb_rccl_get_unique_id(void* id128);
+int eqlb_rccl_comm_create(const void* id128, int32_t nranks, int32_t rank, void** comm);
+void eqlb_rccl_comm_destroy(void* comm);
 
 /* Tiling of the EQLB_SCATTER_TILED launch (built by eqlb_se_set_boundary for plain flux
  * equilibration): number of tiles, owned cells per tile, patch instances (a patch on a tile rim is

@@ -50,12 +50,33 @@ def main():
     ang = np.arctan2(gmesh.x[:, 1] - 0.5, gmesh.x[:, 0] - 0.5)
     owner = np.minimum(((ang + np.pi) / (2 * np.pi) * world).astype(int), world - 1)
     part = dd.Partition(gmesh, owner, rank, world)
+    if mode == "se_local":
+        # the same decomposition from the rank's OWN arrays only (Partition.from_local): local cells, their
+        # coordinates, owner of every local node / cell, global cell ids - what a distributed mesh provides
+        cown = owner[gmesh.cell_nodes].max(axis=1)
+        loc = part.cell_global
+        gn = part.node_global
+        g2l = -np.ones(gmesh.nnodes, dtype=np.int64)
+        g2l[gn] = np.arange(gn.size)
+        part2 = dd.Partition.from_local(gmesh.x[gn, :2], g2l[gmesh.cell_nodes[loc]], owner[gn], cown[loc], loc,
+                                        rank, world, node_global=gn)
+        assert np.array_equal(part2.mesh.cell_nodes, part.mesh.cell_nodes)
+        assert np.array_equal(part2.node_mask, part.node_mask) and np.array_equal(part2.cell_owned, part.cell_owned)
+        assert sorted(part2.send) == sorted(part.send) and sorted(part2.recv) == sorted(part.recv)
+        for q in part.send:
+            assert np.array_equal(part2.send[q], part.send[q])
+        for q in part.recv:
+            assert np.array_equal(part2.recv[q], part.recv[q])
+        assert part2.halo_bytes(nrt) == (8 * nrt * sum(len(v) for v in part.send.values()),
+                                         8 * nrt * sum(len(v) for v in part.recv.values()))
+        part = part2
+        mode = "se"
     m = part.mesh
     assert np.allclose(m.x[m.cell_nodes], gmesh.x[gmesh.cell_nodes[part.cell_global]])
     nd = gG.size // gmesh.ncells
     G = gG.reshape(gmesh.ncells, -1)[part.cell_global].ravel()
     f = gf.reshape(gmesh.ncells, -1)[part.cell_global].ravel()
-    ft = part.facet_types(gft)
+    ft = part.facet_types(gft) if part._gmesh_nfacets else facet_types(m)  # all-Dirichlet data: the local table
     nodes = np.nonzero(part.node_mask)[0]
     nsteps = 2  # accumulating sweeps: ghost rows / DOFs must not be double counted
     if mode == "se":

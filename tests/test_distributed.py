@@ -31,7 +31,7 @@ def test_strip_partition_halo_reduction(oracle_mod, world, n, k):
     assert out.stdout.count("OK") == world
 
 
-@pytest.mark.parametrize("world,mode,k", [(3, "se", 2), (3, "se", 3), (2, "ev", 2), (3, "ev", 1)])
+@pytest.mark.parametrize("world,mode,k", [(3, "se", 2), (3, "se", 3), (2, "ev", 2), (3, "ev", 1), (3, "se_local", 2)])
 def test_general_partition_on_a_delaunay_mesh(oracle_mod, world, mode, k):
     """Partition (any mesh, any node ownership; several neighbours per rank) + halo reduction of the
     broken rows (SE) / the conforming DOFs (EV)."""

@@ -42,5 +42,5 @@ def test_multi_gpu_host_path(rank, world, extra):
         assert d["n_gpus"] == world and d["scaling"] == "weak"
         if not extra:
             assert "behind the interior tiles" in d["config"]["partition"]
-        if "--ev" not in extra:
-            assert d["div_residual_rel"] < 1e-10  # rank 0 receives nothing: its owned rows are complete
+        assert d["div_residual_rel"] < 1e-10  # rank 0 receives nothing: its owned rows (EV: held DOFs) are complete
+        assert d["halo"]["rank0_bytes_sent"] > 0 and d["halo"]["halo_only_ms"] > 0.0

@@ -254,3 +254,53 @@ def test_halo_exchange_class_on_device_with_side_stream_transport(oracle_mod, mo
         assert np.abs(x[part.cell_owned] - ref).max() <= 1e-10 * nsteps * np.abs(gref).max()
         if part.send_cells.size:
             assert np.all(x[part.send_cells] == 0.0)  # ghost rows cleared after packing
+
+
+def test_rccl_transport_self_send_on_one_device():
+    """The library's own transport (eqlb_halo_exchange / eqlb_halo_reduce: ncclGroupStart, ncclSend, ncclRecv,
+    ncclGroupEnd on the caller's communicator and stream) with REAL RCCL calls on one device: a one-rank
+    communicator made through eqlb_rccl_get_unique_id / eqlb_rccl_comm_create, the rank is its own peer - rows A
+    are packed, cleared, sent to rank 0 and added onto rows B.  What it can check here: symbol resolution next to
+    torch's bundled RCCL, argument marshalling of the pointer / count arrays, the 8-byte data type, stream order
+    of pack -> send/recv -> unpack, re-use of the plan across steps.  What it cannot: more than one rank
+    (RCCL refuses two ranks on one device; the multi-rank run is the driver's)."""
+    import torch
+    from dolfinx_eqlb_amd import cpp
+    from dolfinx_eqlb_amd import distributed as dd
+    dev = torch.device("cuda", 0)
+    nrhs, nent, nrt = 2, 1000, 8
+    rng = np.random.default_rng(4)
+    perm = rng.permutation(nent)
+    A, B = np.sort(perm[:137]), np.sort(perm[137:274])
+    comm = cpp.RcclComm(cpp.RcclComm.unique_id(), 1, 0)
+    try:
+        import types
+        part = types.SimpleNamespace(rank=0, send={0: A}, recv={0: B}, mesh=types.SimpleNamespace(ncells=nent))
+        halo = dd.HaloExchange(part, nrt, dev, nrhs, comm=comm)
+        x0 = rng.standard_normal((nrhs, nent, nrt))
+        expect = x0.copy()
+        for mode in ("reduce_rccl", "start_finish", "reduce_rccl"):
+            x = torch.from_numpy(expect.ravel().copy()).to(dev)
+            if mode == "reduce_rccl":
+                halo.reduce_rccl(x)       # one library call
+            else:
+                halo.finish(x, halo.start(x))  # pack + grouped exchange, then unpack (two-phase sweep in between)
+            torch.cuda.synchronize()
+            nxt = expect.copy()
+            nxt[:, B] += expect[:, A]
+            nxt[:, A] = 0.0
+            got = x.cpu().numpy().reshape(nrhs, nent, nrt)
+            assert np.array_equal(got, nxt), mode
+            expect = nxt
+            expect[:, A] = rng.standard_normal((nrhs, A.size, nrt))  # new ghost rows for the next step
+    finally:
+        comm.destroy()
+
+
+def test_rccl_transport_argument_checks():
+    from dolfinx_eqlb_amd import cpp
+    import ctypes as C
+    with pytest.raises(RuntimeError, match="128 bytes"):
+        cpp.RcclComm(b"short", 1, 0)
+    rc = cpp.lib().eqlb_halo_exchange(None, C.c_int32(0), None, None, None, None, None, None)
+    assert rc != 0 and b"eqlb_halo_exchange" in cpp.lib().eqlb_last_error()
