@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--nrhs", type=int, default=1,
                     help="right-hand sides equilibrated by one call (plain fluxes; the reference's multi-RHS test "
                          "uses 4, test_fluxeqlb_multirhs.py:24-186); not the headline")
+    ap.add_argument("--settle", type=int, default=1,
+                    help="1: untimed probes of K steps after the W warmup steps until the step time has settled "
+                         "(clock ramp after the idle set-up phase); 0: none")
     ap.add_argument("--windows", type=int, default=5,
                     help="the K-step window is repeated this many times; value / ms_per_step are those of the FIRST "
                          "window (the contract's timed region), ms_per_step_windows reports min / median / max")
@@ -246,17 +249,19 @@ def main():
     if world > 1 and args.halo == "rccl":
         # a communicator of the library's own (the C++ host's transport, include/eqlb.h: eqlb_halo_exchange): the
         # unique id travels through the torch.distributed group that the launcher set up
-        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-        ok = 1.0
-        try:
-            if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(cpp.RcclComm.unique_id()), dtype=torch.uint8))
-        except RuntimeError:
-            ok = 0.0
+        idt = torch.zeros(129, dtype=torch.uint8, device=dev)  # id + "rank 0 has one" (all ranks must agree
+        if rank == 0:                                            # before the collective ncclCommInitRank)
+            try:
+                idt[:128] = torch.frombuffer(bytearray(cpp.RcclComm.unique_id()), dtype=torch.uint8).to(dev)
+                idt[128] = 1
+            except RuntimeError as e:
+                print(f"[bench] no RCCL unique id through the C ABI ({e}); torch transport", file=sys.stderr, flush=True)
         dist.broadcast(idt, 0)
+        idh = idt.cpu().numpy()
+        ok = float(idh[128])
         if ok:
             try:
-                comm = cpp.RcclComm(idt.cpu().numpy().tobytes(), world, rank)
+                comm = cpp.RcclComm(idh[:128].tobytes(), world, rank)
             except RuntimeError as e:
                 print(f"[bench rank {rank}] RCCL communicator through the C ABI failed ({e}); torch transport",
                       file=sys.stderr, flush=True)
@@ -358,6 +363,23 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    # Clock settle (untimed, reported as `settle_probes`): a GPU that idled through the host-side set-up above
+    # needs more than a millisecond of work to reach the clocks it holds under load - with W = 3 warmup steps
+    # (0.3 ms) the first timed window of round 2 ran 5 - 8 % slower than every later one.  Probes of K steps are
+    # repeated until two consecutive ones agree within 2 % (at most 8); the timed region below is unchanged:
+    # exactly K steps, bracketed by barrier + synchronize.
+    settle = []
+    if args.settle:
+        prev = None
+        for _ in range(8):
+            tp = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            settle.append((time.perf_counter() - tp) / args.steps * 1e3)
+            if prev is not None and abs(settle[-1] - prev) <= 0.02 * prev:
+                break
+            prev = settle[-1]
     barrier()
     # Timed region: K steps back to back.  When a step is ONE kernel launch (tiled / fused launch
     # on one GPU) the kernel's average duration is taken from two HIP events that bracket the whole
@@ -510,6 +532,9 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        "settle_probes": {"n": len(settle), "ms_per_step": [float(v) for v in settle],
+                          "note": "untimed probes of K steps between the W warmup steps and the timed region, "
+                                  "repeated until two agree within 2 % (GPU clocks after the idle set-up)"},
         "ms_per_step_windows": {"n": len(win_ms), "min": float(np.min(win_ms)), "median": float(np.median(win_ms)),
                                 "max": float(np.max(win_ms)), "all": [float(w) for w in win_ms],
                                 "note": "the K-step window repeated; value / ms_per_step are the first window's"},

@@ -98,6 +98,8 @@ void free_boundary(eqlb_se* h)
   dfree(h->facet_type);
   dfree(h->node_ws);
   dfree(h->node_group);
+  dfree(h->node_wslevel);
+  h->ws_levels = 1;
   dfree(h->bvals);
   dfree(h->node_slot);
   dfree(h->node_patch);
@@ -119,12 +121,19 @@ void free_boundary(eqlb_se* h)
 // Grouped boundary patches of the stress path (se/reconstruction.hpp:170-234, se/Patch.cpp:60-104,
 // 762-784; RT_2 only): a node whose two boundary facets carry flux BCs on both stress rows
 // (base/BoundaryData.cpp:611-631) and that has two cells is grouped with the adjacent internal patch.
-// The reference treats the groups one after the other in node order and lets a group see what the
-// earlier ones added to the global stress; on the device all row-wise sweeps come first, which is the
-// same thing as long as no cell of a group's internal patch has a vertex in another group - checked
-// here, overlapping groups are refused.  ws: 0 normal, 1 two-cell member, 2 internal patch.
+// The reference treats the groups one after the other in node order and lets the weak-symmetry step of a
+// group see what the EARLIER groups added to the global stress on the cells of its internal patch
+// (se/solve_patch_weaksym.hpp:100-131 reads the global vector).  On the device all row-wise sweeps come first
+// and every (cell, vertex) contribution keeps its own slot row, so "what has been added so far" is a sum of
+// slot rows: own row + rows of the vertices that are two-cell members of the own group + rows of the vertices
+// that belong to an EARLIER group (group ids are handed out in the reference's discovery order; the patch
+// builder marks those vertices).  The symmetry step of an earlier group has modified the rows of its internal
+// patch, so overlapping groups are ordered: level of a group = 1 + the highest level among the earlier groups
+// that own a vertex of one of its internal patch's cells; the weak-symmetry kernel runs level by level.
+// ws: 0 normal, 1 two-cell member, 2 internal patch; level [nnodes]: level of the node's group (0 elsewhere).
 int find_stress_groups(const eqlb::DeviceMesh& m, const int8_t* facet_type, const uint8_t* node_mask,
-                       std::vector<int8_t>& ws, std::vector<int32_t>& group, bool& any)
+                       std::vector<int8_t>& ws, std::vector<int32_t>& group, std::vector<int8_t>& level,
+                       int& nlevels, bool& any)
 {
   const int32_t nn = m.nnodes;
   ws.assign(nn, 0);
@@ -177,16 +186,37 @@ int find_stress_groups(const eqlb::DeviceMesh& m, const int8_t* facet_type, cons
     ++ngroups;
     any = true;
   }
-  // order independence: the cells of a group's internal patch touch no node of another group
-  for (int32_t node = 0; node < nn && any; ++node)
-    if (ws[node] == 2)
+  // levels of overlapping groups (ascending group id = the reference's order)
+  level.assign(nn, 0);
+  nlevels = 1;
+  if (any)
+  {
+    std::vector<int32_t> inner_of(ngroups, -1);
+    for (int32_t node = 0; node < nn; ++node)
+      if (ws[node] == 2)
+        inner_of[group[node]] = node;
+    std::vector<int> glevel(ngroups, 0);
+    for (int32_t g = 0; g < ngroups; ++g)
+    {
+      const int32_t node = inner_of[g];
+      int lv = 0;
       for (int32_t q = m.h_node_cells_off[node]; q < m.h_node_cells_off[node + 1]; ++q)
         for (int v = 0; v < 3; ++v)
         {
           const int32_t nd = m.h_cell_nodes[3 * (size_t)m.h_node_cells[q] + v];
-          if (group[nd] >= 0 && group[nd] != group[node])
-            return fail(EQLB_ERR_UNSUPPORTED, "overlapping groups of boundary patches (stress equilibration)");
+          if (group[nd] >= 0 && group[nd] < g)
+            lv = std::max(lv, glevel[group[nd]] + 1);
         }
+      glevel[g] = lv;
+      nlevels = std::max(nlevels, lv + 1);
+    }
+    if (nlevels > eqlb::WS_MAX_LEVELS)
+      return fail(EQLB_ERR_UNSUPPORTED, "more than %d levels of overlapping groups of boundary patches",
+                  eqlb::WS_MAX_LEVELS);
+    for (int32_t node = 0; node < nn; ++node)
+      if (group[node] >= 0)
+        level[node] = (int8_t)glevel[group[node]];
+  }
   return EQLB_OK;
 }
 
@@ -1032,6 +1062,12 @@ int eqlb_se_set_option(eqlb_se_t* h, const char* key, int32_t value)
       return fail(EQLB_ERR_INVALID_ARGUMENT, "accumulate must be 0 or 1");
     h->accumulate = value;
   }
+  else if (!strcmp(key, "multi_rhs"))
+  {
+    if (value != 0 && value != 1)
+      return fail(EQLB_ERR_INVALID_ARGUMENT, "multi_rhs must be 0 or 1");
+    h->multi_rhs = value;
+  }
   else if (!strcmp(key, "tile_first"))
   {
     if (value < 0)
@@ -1160,18 +1196,21 @@ try
   a.facet_type = h->facet_type;
   if (h->stress && h->k == 2 && h->stress_flux_bcs)
   {
-    std::vector<int8_t> ws;
+    std::vector<int8_t> ws, lvl;
     std::vector<int32_t> grp;
     bool any = false;
-    const int stg = find_stress_groups(m, facet_type, node_mask, ws, grp, any);
+    h->ws_levels = 1;
+    const int stg = find_stress_groups(m, facet_type, node_mask, ws, grp, lvl, h->ws_levels, any);
     if (stg)
       return stg;
     if (any)
     {
-      if (upload(&h->node_ws, ws.data(), ws.size()) || upload(&h->node_group, grp.data(), grp.size()))
+      if (upload(&h->node_ws, ws.data(), ws.size()) || upload(&h->node_group, grp.data(), grp.size())
+          || upload(&h->node_wslevel, lvl.data(), lvl.size()))
         return EQLB_ERR_DEVICE;
       a.node_ws = h->node_ws;
       a.node_group = h->node_group;
+      a.node_wslevel = h->node_wslevel;
     }
   }
   a.node_slot = h->node_slot;
@@ -1560,17 +1599,20 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
       if (evs && first_bin == 0)
         HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS + 2], stream));
       select_rhs(as, 0, true); // the kernel works on the slot rows of RHS 0 and 1
-      for (int b = first_bin; b < eqlb::MAX_BINS; ++b)
-      {
-        if (h->bins[b].npatch == 0)
-          continue;
-        as.npatch = h->bins[b].npatch;
-        as.slot_offset = h->bins[b].slot_offset;
-        as.patch_offset = h->bins[b].patch_offset;
-        const int st = eqlb::launch_se_weaksym(h->k, h->bins[b].P, !h->stress_flux_bcs, as, stream);
-        if (st)
-          return fail(st, "weak-symmetry kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
-      }
+      // (overlapping groups of boundary patches: one pass per level, a pass skips the patches of other levels)
+      for (int lv = 0; lv < h->ws_levels; ++lv)
+        for (int b = first_bin; b < eqlb::MAX_BINS; ++b)
+        {
+          if (h->bins[b].npatch == 0)
+            continue;
+          as.npatch = h->bins[b].npatch;
+          as.slot_offset = h->bins[b].slot_offset;
+          as.patch_offset = h->bins[b].patch_offset;
+          as.ws_level = lv;
+          const int st = eqlb::launch_se_weaksym(h->k, h->bins[b].P, !h->stress_flux_bcs, as, stream);
+          if (st)
+            return fail(st, "weak-symmetry kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
+        }
       if (evs && first_bin == 0)
         HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS + 3], stream));
     }
@@ -1627,13 +1669,34 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
         return fail(st, "fused stress kernel launch failed");
       r0 = 2;
     }
-    for (int r = r0; r < h->nrhs; ++r)
+    if (h->multi_rhs && h->nrhs - r0 > 1)
     {
-      select_rhs(at, r, false);
-      const int st = eqlb::launch_se_patch_tiled(h->k, h->deg, h->mode, at, ta, stream);
-      if (st)
-        return fail(st, "tiled patch kernel launch failed (k=%d)", h->k);
+      // all (remaining) right-hand sides in one launch per chunk of MULTI_RHS_MAX
+      for (int rb = r0; rb < h->nrhs; rb += eqlb::MULTI_RHS_MAX)
+      {
+        eqlb::MultiRhs mr{};
+        mr.n = std::min(eqlb::MULTI_RHS_MAX, h->nrhs - rb);
+        mr.rhs0 = rb;
+        for (int i = 0; i < mr.n; ++i)
+        {
+          mr.g[i] = d_g[rb + i];
+          mr.f[i] = d_f[rb + i];
+          mr.x[i] = d_x[rb + i];
+        }
+        select_rhs(at, rb, false);
+        const int st = eqlb::launch_se_patch_tiled_multi(h->k, h->deg, h->mode, at, ta, mr, stream);
+        if (st)
+          return fail(st, "tiled multi-RHS patch kernel launch failed (k=%d)", h->k);
+      }
     }
+    else
+      for (int r = r0; r < h->nrhs; ++r)
+      {
+        select_rhs(at, r, false);
+        const int st = eqlb::launch_se_patch_tiled(h->k, h->deg, h->mode, at, ta, stream);
+        if (st)
+          return fail(st, "tiled patch kernel launch failed (k=%d)", h->k);
+      }
     if (evs)
       HIP_TRY(hipEventRecord(evs[1], stream));
     // patches of more than 8 facets of a fused stress launch: generic kernels, sums added (with the last
@@ -2152,7 +2215,8 @@ int eqlb_ev_set_option(eqlb_ev_t* h, const char* key, int32_t value)
     h->se->ev_bv_hier = value;
     return EQLB_OK;
   }
-  if (!strcmp(key, "timing") || !strcmp(key, "scatter") || !strcmp(key, "accumulate") || !strcmp(key, "tile_cells"))
+  if (!strcmp(key, "timing") || !strcmp(key, "scatter") || !strcmp(key, "accumulate") || !strcmp(key, "tile_cells")
+      || !strcmp(key, "multi_rhs"))
     return eqlb_se_set_option(h->se, key, value);
   return fail(EQLB_ERR_INVALID_ARGUMENT, "unknown option '%s'", key);
 }

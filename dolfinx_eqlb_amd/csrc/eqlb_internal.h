@@ -30,6 +30,10 @@ constexpr uint8_t PFLAG_INTERIOR = 1, PFLAG_BC0 = 2, PFLAG_BCN = 4;
 // WS_SKIP: two-cell patch of a group, no weak-symmetry step of its own; WS_GROUP: internal patch of a
 // group, its weak-symmetry step works on own rows + rows of the group's two-cell patches
 constexpr uint8_t PFLAG_WS_SKIP = 8, PFLAG_WS_GROUP = 16;
+// level of the patch's group among overlapping groups (bits 5, 6 of the flag of RHS 0): the weak-symmetry kernel
+// runs once per level, se/reconstruction.hpp:170-234 treats the groups one after the other
+constexpr uint8_t PFLAG_WS_LEVEL_SHIFT = 5;
+constexpr int WS_MAX_LEVELS = 4;
 // slot_info bits 8-10 (plain SoA): local vertex v of the cell belongs to a two-cell patch of the
 // lane's group -> its slot row is added to the stress coefficients (bit 8 + v)
 constexpr uint32_t INFO_GROUPROW_SHIFT = 8;
@@ -82,6 +86,7 @@ struct SeArgs
   int32_t rhs;                // index of the right-hand side handled by this launch (flags, bvals)
   int32_t rhs_in, rhs_out;    // block index of that right-hand side inside flux_dg / rhs_dg and inside out
                               // (0 when the pointers already address the block: lists of separate arrays)
+  int32_t ws_level = 0;       // weak-symmetry kernels: the pass handles the patches of this group level
 };
 
 // bins of a fused launch: blocks [block_start[b], block_start[b+1]) of 256 threads handle bin b
@@ -124,6 +129,16 @@ struct TileArgs
   const double* basis_R;
 };
 
+// right-hand sides of a multi-RHS tiled launch (k_se_patch_tiled_multi)
+constexpr int MULTI_RHS_MAX = 8;
+struct MultiRhs
+{
+  int32_t n, rhs0; // right-hand sides rhs0 .. rhs0 + n - 1 of the handle (boundary flags, boundary values)
+  const double* g[MULTI_RHS_MAX];
+  const double* f[MULTI_RHS_MAX];
+  double* x[MULTI_RHS_MAX];
+};
+
 struct BuildArgs
 {
   int32_t nnodes, nfacets, nrhs;
@@ -142,6 +157,7 @@ struct BuildArgs
   // a group) and the group id
   const int8_t* node_ws;
   const int32_t* node_group;
+  const int8_t* node_wslevel;
   // instance mode (tiled SoA): thread i builds the patch of node inst_node[i] at slot inst_slot[i]
   // as patch i of tile inst_tile[i]; nullptr: one patch per node (node_slot / node_patch)
   int64_t ninst;
@@ -166,6 +182,8 @@ int launch_se_patch(int k, int deg, int P, int solver, int scatter, const SeArgs
 int launch_se_patch_fused(int k, int deg, int scatter, const SeArgs& a, const FusedBins& fb,
                           hipStream_t stream);
 int launch_se_patch_tiled(int k, int deg, int mode, const SeArgs& a, const TileArgs& t, hipStream_t stream);
+int launch_se_patch_tiled_multi(int k, int deg, int mode, const SeArgs& a, const TileArgs& t, const MultiRhs& mr,
+                                hipStream_t stream);
 void launch_tile_facet_owner(const DeviceMesh& m, int64_t n, const int32_t* tile_cells, int32_t* code,
                              hipStream_t stream);
 int tile_cells_of(int k);
@@ -236,6 +254,7 @@ struct eqlb_se
   int nrt = 0, nd = 0;
   int solver = EQLB_SOLVER_SHUFFLE, scatter = EQLB_SCATTER_AUTO, timing = 0, fused = 1;
   int accumulate = 1;               // option "accumulate": 0 stores the result instead of adding it
+  int multi_rhs = 1;                // option "multi_rhs": all right-hand sides of a tiled call in one launch
   int scatter_last = EQLB_SCATTER_SLOTS; // scatter mode the last equilibrate call resolved to
   int mode = 0;                     // 1: constrained-minimisation (EV) patch problems
   int ev_output = 0;                // EV: 0 conforming DOFs, 1 broken hierarchic RT_k layout
@@ -254,6 +273,8 @@ struct eqlb_se
   int8_t* facet_type = nullptr;     // [nrhs][nfacets]
   int8_t* node_ws = nullptr;        // grouped stress patches (stress && k == 2 && groups exist)
   int32_t* node_group = nullptr;
+  int8_t* node_wslevel = nullptr;   // level of the node's group among overlapping groups
+  int ws_levels = 1;                // passes of the weak-symmetry kernel
   double* bvals = nullptr;          // [nrhs][ncells*nrt] global boundary DOFs (nullptr: homogeneous)
   int64_t* node_slot = nullptr;     // [nnodes] first slot of the node's patch or -1
   int64_t* node_patch = nullptr;    // [nnodes] patch index or -1

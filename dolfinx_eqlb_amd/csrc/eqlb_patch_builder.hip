@@ -51,12 +51,16 @@ __global__ void __launch_bounds__(256) k_build_patches(BuildArgs a)
                                       : (uint32_t)(a.cell_pos[c] - tile * a.tile_cells + 1) << INFO_LOCAL_SHIFT;
     if (ws_kind != 2)
       return 0u;
-    // internal patch of a group: mark the vertices of the cell that are two-cell members of it
+    // internal patch of a group: mark the vertices of the cell whose rows belong to "the stress accumulated so
+    // far" (se/solve_patch_weaksym.hpp:100-131): the two-cell members of the own group and every patch of an
+    // EARLIER group (smaller id = treated before this one by se/reconstruction.hpp:170-234)
     uint32_t bits = 0u;
+    const int32_t g = a.node_group[node];
     for (int v = 0; v < 3; ++v)
     {
       const int32_t nd = a.cell_nodes[3 * (int64_t)c + v];
-      if (nd != node && a.node_ws[nd] == 1 && a.node_group[nd] == a.node_group[node])
+      const int32_t gn = a.node_group[nd];
+      if (nd != node && gn >= 0 && ((gn == g && a.node_ws[nd] == 1) || gn < g))
         bits |= 1u << (INFO_GROUPROW_SHIFT + v);
     }
     return bits;
@@ -219,7 +223,7 @@ __global__ void __launch_bounds__(256) k_build_patches(BuildArgs a)
       if (r == 0 && ws_kind == 1)
         fl |= PFLAG_WS_SKIP;
       if (r == 0 && ws_kind == 2)
-        fl |= PFLAG_WS_GROUP;
+        fl |= PFLAG_WS_GROUP | (uint8_t)(a.node_wslevel[node] << PFLAG_WS_LEVEL_SHIFT);
       if (!interior)
       {
         const int8_t* ft = a.facet_type + (int64_t)r * a.nfacets;

@@ -1712,20 +1712,16 @@ __device__ __forceinline__ double packed_sum(const double* rows, int i)
   return rows[la * NPK + (f - ((f > la) ? 1 : 0)) * K + j] + rows[lb * NPK + (f - ((f > lb) ? 1 : 0)) * K + j];
 }
 
+// first half of a tile: the reference tensors into LDS (and the zeroing of the slots where a node mask leaves
+// rows unwritten), ends with the workgroup barrier
 template <int K, int DEG, int MODE>
-__global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patch_tiled(const SeArgs a0, const TileArgs ta)
+__device__ __forceinline__ void tile_stage(const SeArgs& a0, const TileArgs& ta, const int tile, double* lds)
 {
   constexpr int TILE_THREADS = tile_threads_c(K);
-  extern __shared__ __align__(16) double lds[];
   using Z = Sizes<K, DEG, 8>;
   constexpr int NRT = Z::NRT;
-  constexpr int TCMAX = tile_cells_max_c(K); // sizes the register arrays of the flush
-  const int TC = ta.tc;                      // cells per tile of this SoA (<= TCMAX)
+  const int TC = ta.tc;
   constexpr int NPK = NRT - K; // packed (cell, vertex) row: without the facet opposite to the vertex
-  // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, tiles are numbered along the
-  // bisection tree (neighbours in space are neighbours in index); give every XCD one contiguous
-  // range of tiles so that the rim cells two tiles share are read through the same L2
-  const int tile = ta.tile_first + xcd_remap(blockIdx.x, ta.ntiles);
   constexpr bool HALFWQ = K == 3; // as in se_patch_body
   constexpr int NTABL = HALFWQ ? Z::NTAB_HALF : Z::NTAB;
   constexpr int NTABM = NTABL + (MODE ? Z::NEV : 0);
@@ -1754,7 +1750,23 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
     for (int i = threadIdx.x; i < TC * 3 * NPK; i += TILE_THREADS)
       sSlots[i] = 0.0;
   __syncthreads();
+}
 
+// second half: every patch of the tile for ONE right-hand side (a0.rhs, a0.flux_dg, a0.rhs_dg, a0.out), then the
+// flush of the tile's rows
+template <int K, int DEG, int MODE>
+__device__ __forceinline__ void tile_sweep_flush(const SeArgs& a0, const TileArgs& ta, const int tile, double* lds)
+{
+  constexpr int TILE_THREADS = tile_threads_c(K);
+  using Z = Sizes<K, DEG, 8>;
+  constexpr int NRT = Z::NRT;
+  constexpr int TCMAX = tile_cells_max_c(K); // sizes the register arrays of the flush
+  const int TC = ta.tc;                      // cells per tile of this SoA (<= TCMAX)
+  constexpr int NPK = NRT - K;
+  constexpr bool HALFWQ = K == 3;
+  constexpr int NTABL = HALFWQ ? Z::NTAB_HALF : Z::NTAB;
+  constexpr int NTABM = NTABL + (MODE ? Z::NEV : 0);
+  double* sSlots = lds + NTABM;
   const TileDesc& td = ta.tiles[tile];
 #ifndef EQLB_TILE_SOLVER
 #define EQLB_TILE_SOLVER 1
@@ -2046,6 +2058,86 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
         x[xi[it]] = xv[it][0] + packed_sum<K, NPK>(sl, i);
     }
   }
+}
+
+template <int K, int DEG, int MODE>
+__global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patch_tiled(const SeArgs a0, const TileArgs ta)
+{
+  extern __shared__ __align__(16) double lds[];
+  // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, tiles are numbered along the
+  // bisection tree (neighbours in space are neighbours in index); give every XCD one contiguous
+  // range of tiles so that the rim cells two tiles share are read through the same L2
+  const int tile = ta.tile_first + xcd_remap(blockIdx.x, ta.ntiles);
+  tile_stage<K, DEG, MODE>(a0, ta, tile, lds);
+  tile_sweep_flush<K, DEG, MODE>(a0, ta, tile, lds);
+}
+
+// All right-hand sides of a call in ONE launch (se/solve_patch_semiexplt.hpp:1040-1075 loops the right-hand
+// sides inside the patch): the tensors are staged once per tile, then sweep + flush per right-hand side; the
+// tile's descriptors and geometry come from L2 after the first pass.  (What the reference re-uses across the
+// right-hand sides - the factorisation - is a handful of multipliers here; they are recomputed, see DESIGN.md.)
+template <int K, int DEG, int MODE>
+__global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1))
+k_se_patch_tiled_multi(const SeArgs a0, const TileArgs ta, const MultiRhs mr)
+{
+  extern __shared__ __align__(16) double lds[];
+  const int tile = ta.tile_first + xcd_remap(blockIdx.x, ta.ntiles);
+  tile_stage<K, DEG, MODE>(a0, ta, tile, lds);
+  for (int r = 0; r < mr.n; ++r)
+  {
+    SeArgs a = a0;
+    a.rhs = mr.rhs0 + r;
+    a.flux_dg = mr.g[r];
+    a.rhs_dg = mr.f[r];
+    a.out = mr.x[r];
+    a.rhs_in = 0;
+    a.rhs_out = 0;
+    tile_sweep_flush<K, DEG, MODE>(a, ta, tile, lds);
+    __syncthreads(); // the flush has read the slots: the next right-hand side may overwrite them
+  }
+}
+
+template <int K, int DEG, int MODE>
+static int launch_tiled_multi_kd(const SeArgs& a, const TileArgs& t, const MultiRhs& mr, hipStream_t stream)
+{
+  using Z = Sizes<K, DEG, 8>;
+  const size_t lds_bytes
+      = sizeof(double) * ((size_t)(K == 3 ? Z::NTAB_HALF : Z::NTAB) + (MODE ? (size_t)Z::NEV : 0) + (size_t)t.tc * 3 * (Z::NRT - K));
+  if (lds_bytes > 160 * 1024 || t.tc < 1 || t.tc > tile_cells_max_c(K) || mr.n < 1 || mr.n > MULTI_RHS_MAX)
+    return EQLB_ERR_UNSUPPORTED;
+  auto kern = k_se_patch_tiled_multi<K, DEG, MODE>;
+  if (lds_bytes > 64 * 1024)
+  {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+      return EQLB_ERR_DEVICE;
+  }
+  if (t.ntiles == 0)
+    return 0;
+  hipLaunchKernelGGL(kern, dim3((unsigned)t.ntiles), dim3(tile_threads_c(K)), lds_bytes, stream, a, t, mr);
+  return (hipGetLastError() == hipSuccess) ? 0 : EQLB_ERR_DEVICE;
+}
+
+int launch_se_patch_tiled_multi(int k, int deg, int mode, const SeArgs& a, const TileArgs& t, const MultiRhs& mr,
+                                hipStream_t stream)
+{
+  if (mode == 1)
+  {
+    if (k == 1)
+      return launch_tiled_multi_kd<1, 0, 1>(a, t, mr, stream);
+    if (k == 2)
+      return launch_tiled_multi_kd<2, 1, 1>(a, t, mr, stream);
+    if (k == 3)
+      return launch_tiled_multi_kd<3, 2, 1>(a, t, mr, stream);
+    return EQLB_ERR_UNSUPPORTED;
+  }
+  if (k == 1 && deg == 0)
+    return launch_tiled_multi_kd<1, 0, 0>(a, t, mr, stream);
+  if (k == 2 && deg == 1)
+    return launch_tiled_multi_kd<2, 1, 0>(a, t, mr, stream);
+  if (k == 3 && deg == 2)
+    return launch_tiled_multi_kd<3, 2, 0>(a, t, mr, stream);
+  return EQLB_ERR_UNSUPPORTED;
 }
 
 template <int K, int DEG, int MODE>

@@ -83,7 +83,9 @@ __global__ void __launch_bounds__(64) k_se_weaksym(const SeArgs a)
   // two-cell patches of a group have no weak-symmetry step of their own (se/reconstruction.hpp:
   // 181-229: it is imposed once, on the internal patch of the group)
   const uint8_t flag0 = (patch_local < a.npatch) ? a.pflag[patch] : (uint8_t)PFLAG_INTERIOR;
-  const bool pvalid = patch_local < a.npatch && (flag0 & PFLAG_WS_SKIP) == 0;
+  // (patches of another level of overlapping groups are left to that level's pass; plain patches: level 0)
+  const bool pvalid = patch_local < a.npatch && (flag0 & PFLAG_WS_SKIP) == 0
+                      && (int)((flag0 >> PFLAG_WS_LEVEL_SHIFT) & 3) == a.ws_level;
   const bool grouped = (flag0 & PFLAG_WS_GROUP) != 0;
   const int n = pvalid ? (int)a.pn[patch] : 0;
   const bool active = pvalid && sub < n;

@@ -97,7 +97,8 @@ void eqlb_mesh_destroy(eqlb_mesh_t* mesh);
  * the first two RHS are the rows of a stress tensor and the weak symmetry condition is imposed
  * patch-wise after the row-wise equilibration (se/solve_patch_weaksym.hpp:59-233), including the
  * grouped boundary patches for RT_2 with flux BCs on the stress (se/reconstruction.hpp:170-234;
- * groups that overlap are refused with EQLB_ERR_UNSUPPORTED).  k <= 4 (k = 4, the upper end of the
+ * groups that overlap are treated in the reference's node order: one pass of the weak-symmetry kernel per
+ * level of the conflict graph, at most 4 levels).  k <= 4 (k = 4, the upper end of the
  * reference's test range: on patches of up to 8 facets, dense LDS solver, slot path; also stress and EV).  estimate_korn is accepted for symmetry with the
  * reference constructor (the estimate itself is requested per call, see below).
  */
@@ -113,7 +114,9 @@ void eqlb_se_destroy(eqlb_se_t* handle);
  * se/solve_patch_semiexplt.hpp:1157-1160, which assumes a zero-initialised output; 0: flux_hdiv = result,
  * the old values are neither read nor uploaded - every DOF of every cell is written; not with the
  * atomic scatter), "tile_cells" (cells per tile of the tiled launch, 0 = automatic; capped by the LDS of a
- * workgroup; applies to the next eqlb_se_set_boundary - a tuning knob). */
+ * workgroup; applies to the next eqlb_se_set_boundary - a tuning knob), "multi_rhs" (1, default: the tiled
+ * launch sweeps all right-hand sides of a call - the reference loops them inside the patch,
+ * se/solve_patch_semiexplt.hpp:1040-1075; 0: one launch per right-hand side). */
 int eqlb_se_set_option(eqlb_se_t* handle, const char* key, int32_t value);
 
 /*

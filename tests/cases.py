@@ -57,3 +57,36 @@ def bcond_case(mesh_name, k, id_bc):
     ft = gk.elasticity_facet_types(mesh, BCOND_LAYOUTS[id_bc])
     G, f, bv = gk.solve_elasticity(mesh, k, ft, seed=1000 * k + id_bc)
     return mesh, ft, G, f, bv
+
+
+def double_fan_mesh(order=0):
+    """Two interior nodes I1, I2 joined by an edge, eight boundary nodes around them; six of the boundary
+    nodes have two cells.  With flux BCs on the whole boundary for both stress rows the RT_2 stress
+    equilibration forms TWO groups of boundary patches (se/reconstruction.hpp:170-234) whose internal patches
+    (around I1 and I2) overlap: the reference's result depends on the node order, `order` = 1 swaps it."""
+    from dolfinx_eqlb_amd.mesh import create_mesh
+    x = np.array([[-0.5, 0.0], [0.5, 0.05], [1.5, 0.0], [1.0, 1.0], [0.05, 1.0], [-1.0, 1.1], [-1.5, 0.0],
+                  [-1.0, -1.0], [0.0, -1.1], [1.1, -1.0]])
+    i1, i2, b = 0, 1, [2, 3, 4, 5, 6, 7, 8, 9]
+    cells = [[i2, b[0], b[1]], [i2, b[1], b[2]], [i2, b[6], b[7]], [i2, b[7], b[0]],
+             [i1, b[2], b[3]], [i1, b[3], b[4]], [i1, b[4], b[5]], [i1, b[5], b[6]],
+             [i1, i2, b[2]], [i1, b[6], i2]]
+    cells = np.array(cells, dtype=np.int32)
+    if order:
+        perm = np.arange(x.shape[0])[::-1].copy()   # new id of old node i
+        xn = np.empty_like(x)
+        xn[perm] = x
+        x, cells = xn, perm[cells].astype(np.int32)
+    return create_mesh(x, cells)
+
+
+def fan_chain_mesh():
+    """Three interior nodes in a row I1 - I3 - I2, ten boundary nodes, six of them with two cells: with tractions
+    on the whole boundary two groups (around I1 and I2) whose internal patches share NO cell."""
+    from dolfinx_eqlb_amd.mesh import create_mesh
+    x = np.array([[-1.0, 0.0], [1.0, 0.05], [0.0, 0.0], [2.0, 0.0], [1.5, 1.0], [0.5, 1.0], [-0.5, 1.1], [-1.5, 1.0],
+                  [-2.0, 0.0], [-1.5, -1.0], [-0.5, -1.0], [0.5, -1.1], [1.5, -1.0]])
+    i1, i2, i3 = 0, 1, 2
+    cells = [[i2, 3, 4], [i2, 4, 5], [i2, 11, 12], [i2, 12, 3], [i1, 6, 7], [i1, 7, 8], [i1, 8, 9], [i1, 9, 10],
+             [i3, 5, 6], [i3, 10, 11], [i3, i2, 5], [i3, 11, i2], [i1, i3, 6], [i1, 10, i3]]
+    return create_mesh(x, np.array(cells, dtype=np.int32))

@@ -198,6 +198,27 @@ def test_fused_stress_launch_node_mask_and_accumulation(oracle_mod):
     assert np.array_equal(eq.equilibrate_host(G, f, np.full_like(x1, 3.0)), x1)
 
 
+@pytest.mark.parametrize("which", ["chain", "overlap0", "overlap1"])
+def test_stress_groups_on_unstructured_meshes(oracle_mod, which):
+    """Grouped boundary patches off the structured meshes: two groups without a common cell, and two
+    OVERLAPPING groups in both node orders - the device runs the weak-symmetry kernel once per level of the
+    conflict graph and adds the rows of the earlier group, like the reference's sequential node loop
+    (se/reconstruction.hpp:170-234); the numbers are the oracle's (which restates that loop)."""
+    from cases import double_fan_mesh, fan_chain_mesh
+    from dolfinx_eqlb_amd import cpp
+    from synthetic import facet_types, make_compatible_stress_data
+    k = 2
+    mesh = fan_chain_mesh() if which == "chain" else double_fan_mesh(int(which[-1]))
+    ft = np.repeat(facet_types(mesh, lambda mp: np.ones(len(mp), dtype=bool)), 2, axis=0)
+    G, f = make_compatible_stress_data(mesh, k, ft)
+    ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f, stress=True)
+    eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(mesh), k, 2, reconstruct_stress=True)
+    eq.set_boundary(ft)
+    x = eq.equilibrate_host(G, f)
+    assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max()
+    assert np.array_equal(x, eq.equilibrate_host(G, f))
+
+
 def test_fused_stress_after_slot_path_on_the_same_handle(oracle_mod):
     """One handle, scatter 0 (every bin through the slot buffer) and then AUTO (fused tiles + the bins of more
     than 8 lanes through the slots): the rows the first call left in the slot buffer must not be added again."""
