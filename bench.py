@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--settle", type=int, default=1,
                     help="1: untimed probes of K steps after the W warmup steps until the step time has settled "
                          "(clock ramp after the idle set-up phase); 0: none")
+    ap.add_argument("--multi-rhs", type=int, default=1,
+                    help="1 (library default): all right-hand sides of a tiled call in one launch; 0: one launch each")
     ap.add_argument("--windows", type=int, default=5,
                     help="the K-step window is repeated this many times; value / ms_per_step are those of the FIRST "
                          "window (the contract's timed region), ms_per_step_windows reports min / median / max")
@@ -217,14 +219,14 @@ def main():
         eq = cpp.SemiExplicitEquilibrator(dmesh, k, nrhs, reconstruct_stress=args.stress)
         if args.solver is not None:
             eq.set_option("solver", args.solver)
-        if k == 4 and args.solver is None:
-            args.solver = 0  # RT_4 runs on the dense LDS Cholesky path (library default for k = 4)
-        if args.scatter is None:  # the library default (AUTO): tiled launches for k <= 2, also for the stress
+        if args.scatter is None:  # the library default (AUTO): tiled launches for k <= 3, also for the RT_2 stress
             args.scatter = 2 if (k <= 3 and args.solver in (None, 1) and not (args.stress and k != 2)) else 0
         eq.set_option("scatter", args.scatter)
-        fused = (bool(args.fused) and args.solver in (None, 1)) or args.scatter == 2
+        # (k = 4: register solver, one launch per lanes-per-patch bin + slot reduction)
+        fused = (bool(args.fused) and args.solver in (None, 1) and k <= 3) or args.scatter == 2
         eq.set_option("fused", int(fused))
         eq.set_option("accumulate", args.accumulate)
+        eq.set_option("multi_rhs", args.multi_rhs)
         if args.tile_cells:
             eq.set_option("tile_cells", args.tile_cells)
         if world > 1 and args.scatter == 2:
@@ -364,22 +366,24 @@ def main():
         step()
     torch.cuda.synchronize()
     # Clock settle (untimed, reported as `settle_probes`): a GPU that idled through the host-side set-up above
-    # needs more than a millisecond of work to reach the clocks it holds under load - with W = 3 warmup steps
-    # (0.3 ms) the first timed window of round 2 ran 5 - 8 % slower than every later one.  Probes of K steps are
-    # repeated until two consecutive ones agree within 2 % (at most 8); the timed region below is unchanged:
-    # exactly K steps, bracketed by barrier + synchronize.
+    # needs tens of milliseconds of work to reach the clocks it holds under load - with W = 3 warmup steps
+    # (0.3 ms) the first timed window of round 2 ran 5 - 15 % slower than the steady state.  Probes of K steps are
+    # repeated for at least 40 ms and until two consecutive ones agree within 1 % (at most 24); the timed region
+    # below is unchanged: exactly K steps, bracketed by barrier + synchronize.
     settle = []
     if args.settle:
-        prev = None
-        for _ in range(8):
+        # (measured: the step time of the 1M-triangle RT_2 sweep keeps falling for ~30 ms of back-to-back
+        # launches, 0.096 -> 0.081 ms: profiles/r03_settle_probes.txt)
+        t_settle0 = time.perf_counter()
+        while len(settle) < 24:
             tp = time.perf_counter()
             for _ in range(args.steps):
                 step()
             torch.cuda.synchronize()
             settle.append((time.perf_counter() - tp) / args.steps * 1e3)
-            if prev is not None and abs(settle[-1] - prev) <= 0.02 * prev:
+            busy_ms = (time.perf_counter() - t_settle0) * 1e3
+            if len(settle) >= 2 and busy_ms >= 40.0 and abs(settle[-1] - settle[-2]) <= 0.01 * settle[-2]:
                 break
-            prev = settle[-1]
     barrier()
     # Timed region: K steps back to back.  When a step is ONE kernel launch (tiled / fused launch
     # on one GPU) the kernel's average duration is taken from two HIP events that bracket the whole
@@ -475,7 +479,10 @@ def main():
         patch_kernel = None
     bins_ms = None
     if single_kernel:
-        kernels_ms = {patch_kernel + (f" x{nrhs} launches" if nrhs > 1 and not args.stress else ""): step_dev_ms}
+        if nrhs > 1 and not args.stress:
+            patch_kernel = (f"k_se_patch_tiled_multi<K={k}> ({nrhs} right-hand sides)" if args.multi_rhs
+                            else patch_kernel + f" x{nrhs} launches")
+        kernels_ms = {patch_kernel: step_dev_ms}
         timing_method = "two HIP events around the timed region / steps"
     elif two_phase:
         # per-launch event pairs would serialise the two launches of a step against the halo exchange
@@ -534,7 +541,7 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3,
         "settle_probes": {"n": len(settle), "ms_per_step": [float(v) for v in settle],
                           "note": "untimed probes of K steps between the W warmup steps and the timed region, "
-                                  "repeated until two agree within 2 % (GPU clocks after the idle set-up)"},
+                                  "repeated for at least 40 ms and until two agree within 1 % (GPU clocks after the idle set-up)"},
         "ms_per_step_windows": {"n": len(win_ms), "min": float(np.min(win_ms)), "median": float(np.median(win_ms)),
                                 "max": float(np.max(win_ms)), "all": [float(w) for w in win_ms],
                                 "note": "the K-step window repeated; value / ms_per_step are the first window's"},

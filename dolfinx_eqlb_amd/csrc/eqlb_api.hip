@@ -987,8 +987,8 @@ try
   h->stress = reconstruct_stress ? 1 : 0;
   // default result path: tiled launch where it is the fastest (measured)
   h->scatter = EQLB_SCATTER_AUTO;
-  if (k == 4) // three interior unknowns per cell: the register solver condenses at most one
-    h->solver = EQLB_SOLVER_LDS_CHOLESKY;
+  // (k = 4, three interior unknowns per cell: register solver as well since round 3 - 0.38 ms against 14.9 ms of
+  // the dense LDS Cholesky at 250 000 triangles; the EV patch problems at k = 4 stay on the dense solver)
   h->nrt = k * (k + 2);
   h->nd = (degree_dg + 1) * (degree_dg + 2) / 2;
   int st = upload(&h->tables, tab.data(), tab.size());
@@ -1544,7 +1544,7 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
       HIP_TRY(hipMemsetAsync(h->slots, 0, n_slot * 3 * sizeof(double), stream));
     h->slots_first_bin = first_bin;
     eqlb::SeArgs as = a;
-    if ((h->mode == 1 && h->k <= 3) || (h->fused && h->solver == EQLB_SOLVER_SHUFFLE))
+    if ((h->mode == 1 && h->k <= 3) || (h->fused && h->solver == EQLB_SOLVER_SHUFFLE && h->k <= 3))
     {
       // all bins in one launch; timing slot 0 holds the fused kernel
       eqlb::FusedBins fb{};
@@ -1723,7 +1723,7 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
     if (h->stress)
       return fail(EQLB_ERR_UNSUPPORTED, "stress equilibration needs the slot or the tiled scatter");
     eqlb::SeArgs aa = a;
-    if (h->fused && h->solver == EQLB_SOLVER_SHUFFLE)
+    if (h->fused && h->solver == EQLB_SOLVER_SHUFFLE && h->k <= 3)
     {
       eqlb::FusedBins fb{};
       int64_t nb = 0;
@@ -1845,7 +1845,7 @@ double eqlb_se_last_kernel_ms(const eqlb_se_t* h, int32_t which)
   if (which == eqlb::MAX_BINS + 1 && !h->stress)
     return 0.0;
   const bool fused_run = (h->mode == 1 && h->k <= 3) || h->scatter_last == EQLB_SCATTER_TILED
-                         || (h->fused && h->solver == EQLB_SOLVER_SHUFFLE);
+                         || (h->fused && h->solver == EQLB_SOLVER_SHUFFLE && h->k <= 3);
   if (which < eqlb::MAX_BINS && ((fused_run && which != 0) || (!fused_run && h->bins[which].npatch == 0)))
     return 0.0;
   if (which == eqlb::MAX_BINS && h->scatter_last != EQLB_SCATTER_SLOTS)
@@ -2173,6 +2173,8 @@ try
   if (st)
     return st;
   se->mode = 1;
+  if (k == 4)
+    se->solver = EQLB_SOLVER_LDS_CHOLESKY; // MODE 1 of the register solver is instantiated for k <= 3
   se->ev_ndofs = (int64_t)mesh->m.nfacets * k + (int64_t)mesh->m.ncells * (k * k - k);
   eqlb_ev* h = new eqlb_ev();
   h->se = se;

@@ -179,6 +179,10 @@ struct Sizes
   }
   static constexpr int block_of(int solver)
   {
+    // register solver at k = 4: the 80 KB of tensors are staged once per workgroup - as many waves as possible
+    // behind them (two workgroups of 256 threads share a CU's 160 KB)
+    if (K >= 4 && solver != 0 && P < 32)
+      return 256;
     return (P >= 32) ? 64
                      : ((lds_doubles(256, solver) * 8 <= 65536)
                             ? 256

@@ -99,6 +99,9 @@ int fill_tables_host(int k, int deg, std::vector<double>& out)
   return (out.size() == table_doubles(k, deg)) ? 0 : EQLB_ERR_UNSUPPORTED;
 }
 
+#ifndef EQLB_P2_DIV_NODAL
+#define EQLB_P2_DIV_NODAL 1 // P2 data: divergence of the projected flux through its nodal values instead of the tensor D
+#endif
 #ifndef EQLB_CHAIN_PCR
 #define EQLB_CHAIN_PCR 1 // RT_2 chain solve by parallel cyclic reduction (0: sequential elimination)
 #endif
@@ -329,17 +332,17 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
             const double jt0 = J00 * g2.x + J10 * g2.y, jt1 = J01 * g2.x + J11 * g2.y; // J^T G_i
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
-              Rq[q] += fd * tH[i * NQ + q] + gg * sHG[i * NQ + q];
+              Rq[q] = __builtin_fma(gg, sHG[i * NQ + q], __builtin_fma(fd, tH[i * NQ + q], Rq[q]));
 #pragma unroll
             for (int h = 0; h < NH; ++h)
             {
               if constexpr (AL)
               {
                 const double2 w2 = reinterpret_cast<const double2*>(wg)[h * ND + i];
-                LeG[h] += w2.x * jt0 + w2.y * jt1;
+                LeG[h] = __builtin_fma(w2.y, jt1, __builtin_fma(w2.x, jt0, LeG[h]));
               }
               else
-                LeG[h] += wg[(h * ND + i) * 2] * jt0 + wg[(h * ND + i) * 2 + 1] * jt1;
+                LeG[h] = __builtin_fma(wg[(h * ND + i) * 2 + 1], jt1, __builtin_fma(wg[(h * ND + i) * 2], jt0, LeG[h]));
             }
           }
         }
@@ -351,8 +354,11 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         const double* tH = row16<AL>(sH + ln * Z::HROW);
         const double* tD = sD + ln * ND * 2 * NQ;
         double fdv[ND], dvg = 0.0;
+        double ax[(DEG == 2) ? ND : 1], by[(DEG == 2) ? ND : 1];
         (void)fdv;
         (void)tD;
+        (void)ax;
+        (void)by;
 #pragma unroll
         for (int i = 0; i < ND; ++i)
         {
@@ -396,11 +402,41 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
             else
               dvg += gh1;
           }
+          else if constexpr (DEG == 2 && EQLB_P2_DIV_NODAL)
+          {
+            // P2 data: div_ref(adj G) is in P1, hence exactly representable by its values at the six P2 nodes -
+            // three vertex values from the derivatives of the P2 basis there (constants of the reference element,
+            // node order of elmtlib/lagrange.py: vertices, then the edges (v1,v2), (v0,v2), (v0,v1)), the edge
+            // values are their means.  Replaces the contraction with the tensor D: 72 -> 24 multiply-adds per lane
+            // and no reads of D.
+            fdv[i] = fd;
+            ax[i] = gh0;
+            by[i] = gh1;
+          }
           else
           {
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
-              Rq[q] += fd * tH[i * NQ + q] - gh0 * tD[(i * 2 + 0) * NQ + q] - gh1 * tD[(i * 2 + 1) * NQ + q];
+              Rq[q] = __builtin_fma(-gh1, tD[(i * 2 + 1) * NQ + q],
+                                    __builtin_fma(-gh0, tD[(i * 2 + 0) * NQ + q], __builtin_fma(fd, tH[i * NQ + q], Rq[q])));
+          }
+        }
+        if constexpr (DEG == 2 && EQLB_P2_DIV_NODAL)
+        {
+          double dvn[ND];
+          dvn[0] = 4.0 * (ax[5] + by[4]) - 3.0 * (ax[0] + by[0]) - ax[1] - by[2];
+          dvn[1] = ax[0] + by[0] + 3.0 * ax[1] - by[2] + 4.0 * (by[3] - by[5] - ax[5]);
+          dvn[2] = ax[0] + by[0] - ax[1] + 3.0 * by[2] + 4.0 * (ax[3] - ax[4] - by[4]);
+          dvn[3] = 0.5 * (dvn[1] + dvn[2]);
+          dvn[4] = 0.5 * (dvn[0] + dvn[2]);
+          dvn[5] = 0.5 * (dvn[0] + dvn[1]);
+#pragma unroll
+          for (int i = 0; i < ND; ++i)
+          {
+            const double w = fdv[i] - dvn[i];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+              Rq[q] = __builtin_fma(w, tH[i * NQ + q], Rq[q]);
           }
         }
         if constexpr (DEG == 1)
@@ -642,9 +678,10 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
             const double2 w1 = reinterpret_cast<const double2*>(wq + (NH + h) * NCOLS)[c2];
             const double2 w2 = reinterpret_cast<const double2*>(wq + (2 * NH + h) * NCOLS)[c2];
             const double f0 = full[2 * c2], f1 = (2 * c2 + 1 < NCOL) ? full[2 * c2 + 1] : 0.0; // pad column
-            s0 += w0.x * f0 + w0.y * f1;
-            s1 += w1.x * f0 + w1.y * f1;
-            s2 += w2.x * f0 + w2.y * f1;
+            // (two fused multiply-adds per sum: "s += a * b + c * d" compiles to mul + fma + add)
+            s0 = __builtin_fma(w0.y, f1, __builtin_fma(w0.x, f0, s0));
+            s1 = __builtin_fma(w1.y, f1, __builtin_fma(w1.x, f0, s1));
+            s2 = __builtin_fma(w2.y, f1, __builtin_fma(w2.x, f0, s2));
           }
         }
         else
@@ -865,7 +902,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       // ---- SOLVER 1: everything in registers, lane-to-lane hand-off by shuffles ----
       // Unknown layout: border z = [d ; x_0] (x_i = the KB higher moments of facet E_i), chain
       // x_1 .. x_{nf-1} block tridiagonal.  Lane i holds the block row of facet E_i.
-      static_assert(NADD <= 1, "interior-DOF condensation is written for at most one DOF per cell");
+      static_assert(NADD <= 3, "interior-DOF condensation is written for at most three DOFs per cell (k <= 4)");
       constexpr int W = K;         // border width
       constexpr int NC = 1 + 2 * KB; // core local unknowns [d | um | up]
       const bool fx_m = (bc0 && sub == 0) || (bcn && sub == n); // facet E_sub fixed (flux BC)
@@ -895,27 +932,130 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
           }
         }
       }
-      // (b) static condensation of the cell-interior unknown (k >= 3)
-      double ca[NC], la = 0.0;
+      // (b) static condensation of the cell-interior unknowns (k = 3: one, k = 4: three per cell)
+      constexpr int NA1 = (NADD > 0) ? NADD : 1;
+      double ca[NC][NA1], la[NA1];
 #pragma unroll
       for (int h = 0; h < NC; ++h)
-        ca[h] = 0.0;
+#pragma unroll
+        for (int q = 0; q < NA1; ++q)
+          ca[h][q] = 0.0;
+#pragma unroll
+      for (int q = 0; q < NA1; ++q)
+        la[q] = 0.0;
       if constexpr (NADD == 1)
       {
         const double piv = active ? T[NC][NC] : 1.0;
         const double ip = rcp_d(piv);
-        la = Lv[NC] * ip;
+        la[0] = Lv[NC] * ip;
 #pragma unroll
         for (int h = 0; h < NC; ++h)
-          ca[h] = T[h][NC] * ip;
+          ca[h][0] = T[h][NC] * ip;
 #pragma unroll
         for (int h = 0; h < NC; ++h)
         {
-          Lv[h] -= T[h][NC] * la;
+          Lv[h] -= T[h][NC] * la[0];
 #pragma unroll
           for (int g = 0; g <= h; ++g) // symmetric update: one triangle, mirrored
           {
-            const double v = T[h][g] - ca[h] * T[NC][g];
+            const double v = T[h][g] - ca[h][0] * T[NC][g];
+            T[h][g] = v;
+            T[g][h] = v;
+          }
+        }
+      }
+      else if constexpr (NADD > 1)
+      {
+        // inverse of the SPD interior block by Cholesky (L L^T = T_ii, inactive lanes: identity), then
+        // ca = T_ci T_ii^-1, la = T_ii^-1 L_i, Schur update of the core block and load
+        double Li[NADD][NADD], iLd[NADD], Inv[NADD][NADD];
+#pragma unroll
+        for (int i = 0; i < NADD; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j)
+            Li[i][j] = active ? T[NC + i][NC + j] : ((i == j) ? 1.0 : 0.0);
+#pragma unroll
+        for (int j = 0; j < NADD; ++j)
+        {
+          double dj = Li[j][j];
+#pragma unroll
+          for (int q = 0; q < j; ++q)
+            dj -= Li[j][q] * Li[j][q];
+          if (!(dj > 0.0))
+          {
+            status_local = pvalid ? 1 : status_local;
+            dj = 1.0;
+          }
+          const double ilj = rsqrt_d(dj);
+          Li[j][j] = dj * ilj;
+          iLd[j] = ilj;
+#pragma unroll
+          for (int i = j + 1; i < NADD; ++i)
+          {
+            double v = Li[i][j];
+#pragma unroll
+            for (int q = 0; q < j; ++q)
+              v -= Li[i][q] * Li[j][q];
+            Li[i][j] = v * ilj;
+          }
+        }
+        // columns of the inverse: L L^T x = e_c
+#pragma unroll
+        for (int c = 0; c < NADD; ++c)
+        {
+          double y[NADD];
+#pragma unroll
+          for (int i = 0; i < NADD; ++i)
+          {
+            double v = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int q = 0; q < i; ++q)
+              v -= Li[i][q] * y[q];
+            y[i] = v * iLd[i];
+          }
+#pragma unroll
+          for (int i = NADD - 1; i >= 0; --i)
+          {
+            double v = y[i];
+#pragma unroll
+            for (int q = i + 1; q < NADD; ++q)
+              v -= Li[q][i] * Inv[q][c];
+            Inv[i][c] = v * iLd[i];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NADD; ++q)
+        {
+          double v = 0.0;
+#pragma unroll
+          for (int q2 = 0; q2 < NADD; ++q2)
+            v += Inv[q][q2] * Lv[NC + q2];
+          la[q] = v;
+        }
+#pragma unroll
+        for (int h = 0; h < NC; ++h)
+#pragma unroll
+          for (int q = 0; q < NADD; ++q)
+          {
+            double v = 0.0;
+#pragma unroll
+            for (int q2 = 0; q2 < NADD; ++q2)
+              v += T[h][NC + q2] * Inv[q2][q];
+            ca[h][q] = v;
+          }
+#pragma unroll
+        for (int h = 0; h < NC; ++h)
+        {
+#pragma unroll
+          for (int q = 0; q < NADD; ++q)
+            Lv[h] -= T[h][NC + q] * la[q];
+#pragma unroll
+          for (int g = 0; g <= h; ++g)
+          {
+            double v = T[h][g];
+#pragma unroll
+            for (int q = 0; q < NADD; ++q)
+              v -= ca[h][q] * T[NC + q][g];
             T[h][g] = v;
             T[g][h] = v;
           }
@@ -1068,6 +1208,24 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         auto finish_row = [&]() {
           if constexpr (KB == 1)
             Ei[0][0] = rcp_d(Dp[0][0]);
+          else if constexpr (KB == 3)
+          {
+            // symmetric 3 x 3: adjugate / determinant
+            const double c00 = Dp[1][1] * Dp[2][2] - Dp[1][2] * Dp[2][1];
+            const double c01 = Dp[0][2] * Dp[2][1] - Dp[0][1] * Dp[2][2];
+            const double c02 = Dp[0][1] * Dp[1][2] - Dp[0][2] * Dp[1][1];
+            const double c11 = Dp[0][0] * Dp[2][2] - Dp[0][2] * Dp[2][0];
+            const double c12 = Dp[0][2] * Dp[1][0] - Dp[0][0] * Dp[1][2];
+            const double c22 = Dp[0][0] * Dp[1][1] - Dp[0][1] * Dp[1][0];
+            const double det = Dp[0][0] * c00 + Dp[0][1] * c01 + Dp[0][2] * c02;
+            const double id = rcp_d(det);
+            Ei[0][0] = c00 * id;
+            Ei[0][1] = Ei[1][0] = c01 * id;
+            Ei[0][2] = Ei[2][0] = c02 * id;
+            Ei[1][1] = c11 * id;
+            Ei[1][2] = Ei[2][1] = c12 * id;
+            Ei[2][2] = c22 * id;
+          }
           else
           {
             const double det = Dp[0][0] * Dp[1][1] - Dp[0][1] * Dp[1][0];
@@ -1384,13 +1542,17 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         ul[1 + aa] = xs[aa];
         ul[1 + KB + aa] = shfl_d(xs[aa], gbase + ((fi_p < P) ? fi_p : 0));
       }
-      if constexpr (NADD == 1)
+      if constexpr (NADD >= 1)
       {
-        double v = la;
 #pragma unroll
-        for (int h = 0; h < NC; ++h)
-          v -= ca[h] * ul[h];
-        ul[NC] = v;
+        for (int q = 0; q < NADD; ++q)
+        {
+          double v = la[q];
+#pragma unroll
+          for (int h = 0; h < NC; ++h)
+            v -= ca[h][q] * ul[h];
+          ul[NC + q] = v;
+        }
       }
       if (!active)
       {
@@ -2073,28 +2235,30 @@ __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1)) k_se_patc
 }
 
 // All right-hand sides of a call in ONE launch (se/solve_patch_semiexplt.hpp:1040-1075 loops the right-hand
-// sides inside the patch): the tensors are staged once per tile, then sweep + flush per right-hand side; the
-// tile's descriptors and geometry come from L2 after the first pass.  (What the reference re-uses across the
-// right-hand sides - the factorisation - is a handful of multipliers here; they are recomputed, see DESIGN.md.)
+// sides inside the patch): a workgroup per (tile, right-hand side); the workgroups of one tile are neighbours in
+// the launch order of their XCD, so the tile's descriptors, geometry and tensors are read from HBM once and
+// come from that XCD's L2 for the other right-hand sides.  A loop over the right-hand sides INSIDE the
+// workgroup was built and measured first (tensors staged once per tile): the loop makes the compiler hoist
+// lane predicates and table addresses out of it, 47 spilled registers, 0.565 ms for 4 right-hand sides at 1M
+// triangles against 0.357 ms for four separate launches.  What the reference re-uses across the
+// right-hand sides - the factorisation - is a handful of multipliers here; they are recomputed.
 template <int K, int DEG, int MODE>
 __global__ void __launch_bounds__(tile_threads_c(K), (K <= 2 ? 4 : 1))
 k_se_patch_tiled_multi(const SeArgs a0, const TileArgs ta, const MultiRhs mr)
 {
   extern __shared__ __align__(16) double lds[];
-  const int tile = ta.tile_first + xcd_remap(blockIdx.x, ta.ntiles);
-  tile_stage<K, DEG, MODE>(a0, ta, tile, lds);
-  for (int r = 0; r < mr.n; ++r)
-  {
-    SeArgs a = a0;
-    a.rhs = mr.rhs0 + r;
-    a.flux_dg = mr.g[r];
-    a.rhs_dg = mr.f[r];
-    a.out = mr.x[r];
-    a.rhs_in = 0;
-    a.rhs_out = 0;
-    tile_sweep_flush<K, DEG, MODE>(a, ta, tile, lds);
-    __syncthreads(); // the flush has read the slots: the next right-hand side may overwrite them
-  }
+  const int pos = xcd_remap(blockIdx.x, ta.ntiles * mr.n);
+  const int tile = ta.tile_first + pos / mr.n;
+  const int r = pos - (pos / mr.n) * mr.n;
+  SeArgs a = a0;
+  a.rhs = mr.rhs0 + r;
+  a.flux_dg = mr.g[r];
+  a.rhs_dg = mr.f[r];
+  a.out = mr.x[r];
+  a.rhs_in = 0;
+  a.rhs_out = 0;
+  tile_stage<K, DEG, MODE>(a, ta, tile, lds);
+  tile_sweep_flush<K, DEG, MODE>(a, ta, tile, lds);
 }
 
 template <int K, int DEG, int MODE>
@@ -2114,7 +2278,7 @@ static int launch_tiled_multi_kd(const SeArgs& a, const TileArgs& t, const Multi
   }
   if (t.ntiles == 0)
     return 0;
-  hipLaunchKernelGGL(kern, dim3((unsigned)t.ntiles), dim3(tile_threads_c(K)), lds_bytes, stream, a, t, mr);
+  hipLaunchKernelGGL(kern, dim3((unsigned)t.ntiles * (unsigned)mr.n), dim3(tile_threads_c(K)), lds_bytes, stream, a, t, mr);
   return (hipGetLastError() == hipSuccess) ? 0 : EQLB_ERR_DEVICE;
 }
 
@@ -2319,9 +2483,18 @@ int launch_se_patch_fused(int k, int deg, int scatter, const SeArgs& a, const Fu
   return EQLB_ERR_UNSUPPORTED;
 }
 
-// k = 4 (three interior unknowns per cell): dense LDS Cholesky only, patches of up to 8 facets
+// k = 4 (three interior unknowns per cell).  Register solver (three interior unknowns condensed per cell, 3 x 3
+// blocks handed down the chain): every lanes-per-patch bin, slots or atomics.  Dense LDS Cholesky: patches of up to
+// 8 facets (its tile of 52 x 52 / 2 doubles per patch and the 80 KB of RT_4 tensors fill the LDS); the only path of
+// the EV patch problems at k = 4.
 static int launch_k4(int P, int solver, int scatter, const SeArgs& a, hipStream_t stream, int mode)
 {
+  if (solver == EQLB_SOLVER_SHUFFLE && mode == 0)
+  {
+    if (scatter == EQLB_SCATTER_SLOTS)
+      return launch_p<4, 3, 1, 0>(P, a, stream);
+    return launch_p<4, 3, 1, 1>(P, a, stream);
+  }
   if (solver != EQLB_SOLVER_LDS_CHOLESKY || (P != 4 && P != 8))
     return EQLB_ERR_UNSUPPORTED;
   if (mode == 1) // constrained-minimisation patch problems (slots only)

@@ -443,9 +443,9 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
         for (int r = 0; r < 2; ++r)
         {
           const double f0 = full[r][2 * c2], f1 = full[r][2 * c2 + 1];
-          s[r][0] += w0.x * f0 + w0.y * f1;
-          s[r][1] += w1.x * f0 + w1.y * f1;
-          s[r][2] += w2.x * f0 + w2.y * f1;
+          s[r][0] = __builtin_fma(w0.y, f1, __builtin_fma(w0.x, f0, s[r][0]));
+          s[r][1] = __builtin_fma(w1.y, f1, __builtin_fma(w1.x, f0, s[r][1]));
+          s[r][2] = __builtin_fma(w2.y, f1, __builtin_fma(w2.x, f0, s[r][2]));
         }
       }
 #pragma unroll
@@ -657,7 +657,7 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
       v += ring_prev(Brow[k][2] * tc_);
       v += ring_next_nc(Brow[k][0] * tc_);
       // border part q^(r)^T Zs^-1 q^(c)
-      v += q0 * from_lane(z0, gbase + c) + q1 * from_lane(z1, gbase + c);
+      v = __builtin_fma(q1, from_lane(z1, gbase + c), __builtin_fma(q0, from_lane(z0, gbase + c), v));
       asm volatile("" : "+v"(v)); // keeps the exchanges of the columns apart (register pressure)
       rv[1 + c] += v;
     }

@@ -98,15 +98,17 @@ void eqlb_mesh_destroy(eqlb_mesh_t* mesh);
  * patch-wise after the row-wise equilibration (se/solve_patch_weaksym.hpp:59-233), including the
  * grouped boundary patches for RT_2 with flux BCs on the stress (se/reconstruction.hpp:170-234;
  * groups that overlap are treated in the reference's node order: one pass of the weak-symmetry kernel per
- * level of the conflict graph, at most 4 levels).  k <= 4 (k = 4, the upper end of the
- * reference's test range: on patches of up to 8 facets, dense LDS solver, slot path; also stress and EV).  estimate_korn is accepted for symmetry with the
- * reference constructor (the estimate itself is requested per call, see below).
+ * level of the conflict graph, at most 4 levels).  k <= 4 (k = 4 is the upper end of the reference's test
+ * range: register solver with the three interior unknowns of a cell condensed, every lanes-per-patch bin, slot
+ * path; the weak-symmetry step and the EV patch problems at k = 4 run on the dense LDS solver, patches of up to 8
+ * facets).  estimate_korn is accepted for symmetry with the reference constructor (the estimate itself is
+ * requested per call, see below).
  */
 int eqlb_se_create(eqlb_mesh_t* mesh, int32_t k, int32_t degree_dg, int32_t nrhs,
                    int32_t reconstruct_stress, int32_t estimate_korn, eqlb_se_t** handle);
 void eqlb_se_destroy(eqlb_se_t* handle);
 
-/* Integer options: "solver" (EQLB_SOLVER_*; default SHUFFLE, LDS_CHOLESKY for k = 4), "scatter"
+/* Integer options: "solver" (EQLB_SOLVER_*; default SHUFFLE; LDS_CHOLESKY for the EV problems at k = 4), "scatter"
  * (EQLB_SCATTER_*; default AUTO), "fused" (1: all patch-size bins of the slot path in one launch,
  * default), "timing" (1: record HIP events around the kernels, see eqlb_se_last_kernel_ms),
  * "tile_first" / "tile_count" (range of tiles swept by the next tiled launches, default 0 / -1 = all;

@@ -269,20 +269,40 @@ def test_geometry_scaling_and_offset(cpp, oracle_mod, scale, shift):
         assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("solver", [0, 1])
 @pytest.mark.parametrize("bc", ["dirichlet", "neumann_lt", "neumann_bottom"])
-def test_k4_matches_oracle(cpp, oracle_mod, bc):
-    """RT_4 (three interior unknowns per cell): dense LDS Cholesky path, patches of up to 8 facets
-    (the reference's tests go up to k = 4, python/test/unit/test_fluxeqlb_conditions.py)."""
+def test_k4_matches_oracle(cpp, oracle_mod, bc, solver):
+    """RT_4 (three interior unknowns per cell; the reference's tests go up to k = 4,
+    python/test/unit/test_fluxeqlb_conditions.py): dense LDS Cholesky (patches of up to 8 facets) and the register
+    solver (interior unknowns condensed per cell, 3 x 3 blocks down the chain)."""
     k = 4
     mesh, ft, G, f = make_case(5, k, bc)
     ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f)
     eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(mesh), k, 1)
+    eq.set_option("solver", solver)
     eq.set_boundary(ft)
     x = eq.equilibrate_host(G, f)
     assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max()
     from dolfinx_eqlb_amd.eqlb import check_eqlb_conditions as chk
     res, nrm = chk.divergence_residual(mesh, k, x[0], G[0], f[0])
     assert res < 1e-10 * nrm and chk.check_jump_condition(mesh, k, x[0], G[0], atol=1e-9)
+
+
+@pytest.mark.parametrize("ns", [12, 24])
+def test_k4_patches_of_more_than_8_facets(cpp, oracle_mod, ns):
+    """RT_4 on a patch of valence 12 / 24 (lanes-per-patch bins 16 / 32): register solver only."""
+    from dolfinx_eqlb_amd.mesh import create_disk
+    from synthetic import facet_types, make_compatible_data
+    k = 4
+    mesh = create_disk(ns, 2, shuffle_seed=9)
+    ft = facet_types(mesh, None)
+    G, f = make_compatible_data(mesh, k, ft, seed=4)
+    eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(mesh), k, 1)
+    eq.set_option("solver", 1)
+    eq.set_boundary(ft)
+    x = eq.equilibrate_host(G[None], f[None])
+    ref = oracle_mod.se_reconstruct(mesh, k, ft, G[None], f[None])
+    assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max()
 
 
 def test_invalid_connectivity_is_refused(cpp):
@@ -365,3 +385,30 @@ def test_timing_only_solver_is_not_in_the_product_build(cpp):
     eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(mesh), 2, 1)
     with pytest.raises(RuntimeError, match="unknown solver"):
         eq.set_option("solver", 9)
+
+
+@pytest.mark.parametrize("k,nrhs", [(1, 3), (2, 4), (2, 9), (3, 2)])
+def test_multi_rhs_launch_equals_one_launch_per_rhs(cpp, oracle_mod, k, nrhs):
+    """All right-hand sides of a tiled call in ONE launch (k_se_patch_tiled_multi, the default; the reference
+    loops the right-hand sides inside the patch, se/solve_patch_semiexplt.hpp:1040-1075) against one launch per
+    right-hand side: bitwise equal, different boundary types per right-hand side (the reference's multi-RHS
+    test, test_fluxeqlb_multirhs.py:24-186, uses 4), more than the 8 of one launch chunk, several tiles."""
+    from cases import BCS
+    from dolfinx_eqlb_amd.mesh import create_unit_square
+    from synthetic import facet_types, make_compatible_data
+    mesh = create_unit_square(14, shuffle_seed=3, perturb=0.2)
+    names = ["neumann_lt", "dirichlet", "neumann_bottom"]
+    fts = [facet_types(mesh, BCS[names[i % 3]])[0] for i in range(nrhs)]
+    data = [make_compatible_data(mesh, k, ft[None], seed=11 + i) for i, ft in enumerate(fts)]
+    ft = np.stack(fts)
+    G = np.stack([d[0] for d in data])
+    f = np.stack([d[1] for d in data])
+    out = []
+    for multi in (1, 0):
+        eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(mesh), k, nrhs)
+        eq.set_option("multi_rhs", multi)
+        eq.set_boundary(ft)
+        out.append(eq.equilibrate_host(G, f))
+    assert np.array_equal(out[0], out[1])
+    ref = oracle_mod.se_reconstruct(mesh, k, ft, G, f)
+    assert np.abs(out[0] - ref).max() <= RTOL * np.abs(ref).max()
