@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "eqlb_se_equilibrate_lists", "eqlb_ev_equilibrate_lists", "eqlb_se_kornconst",
     "eqlb_ev_set_basis_transform", "eqlb_se_estimate_stress", "eqlb_oscillation",
     "eqlb_halo_exchange", "eqlb_halo_reduce", "eqlb_rccl_get_unique_id", "eqlb_rccl_comm_create",
-    "eqlb_rccl_comm_destroy",
+    "eqlb_rccl_comm_destroy", "eqlb_halo_create", "eqlb_halo_destroy", "eqlb_halo_bytes", "eqlb_halo_reduce_plan",
 ]
 
 _lib = None
@@ -82,7 +82,8 @@ def lib():
         L.eqlb_ev_num_dofs.restype = C.c_int64
         L.eqlb_ev_num_patches.restype = C.c_int64
         L.eqlb_ev_last_kernel_ms.restype = C.c_double
-        for name in ("eqlb_mesh_destroy", "eqlb_se_destroy", "eqlb_ev_destroy"):
+        for name in ("eqlb_mesh_destroy", "eqlb_se_destroy", "eqlb_ev_destroy", "eqlb_halo_destroy",
+                     "eqlb_rccl_comm_destroy"):
             getattr(L, name).restype = None
         _lib = L
     return _lib

@@ -2173,8 +2173,6 @@ try
   if (st)
     return st;
   se->mode = 1;
-  if (k == 4)
-    se->solver = EQLB_SOLVER_LDS_CHOLESKY; // MODE 1 of the register solver is instantiated for k <= 3
   se->ev_ndofs = (int64_t)mesh->m.nfacets * k + (int64_t)mesh->m.ncells * (k * k - k);
   eqlb_ev* h = new eqlb_ev();
   h->se = se;

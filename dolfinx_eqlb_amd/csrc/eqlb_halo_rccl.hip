@@ -14,7 +14,9 @@
 
 #include <climits>
 #include <cstring>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <vector>
 
 #define fail eqlb::set_error
@@ -196,6 +198,120 @@ int eqlb_halo_reduce(void* comm, int32_t nrhs, int32_t nrt, int64_t nentries, do
   if (hipGetLastError() != hipSuccess)
     return fail(EQLB_ERR_DEVICE, "eqlb_halo_reduce: unpack kernel launch failed");
   return EQLB_OK;
+}
+
+// ---- halo plan: the lists on the device and the staging buffers, owned by the library -----------------
+struct eqlb_halo
+{
+  int32_t nrhs = 0, nrt = 0, npeers = 0;
+  int64_t nentries = 0;
+  std::vector<int32_t> peers;
+  std::vector<int64_t> nsend, nrecv;
+  std::vector<int64_t*> send_idx, recv_idx; // device
+  std::vector<double*> send_buf, recv_buf;  // device
+};
+
+int eqlb_halo_create(int32_t nrhs, int32_t nrt, int64_t nentries, int32_t npeers, const int32_t* peers,
+                     const int64_t* const* send_idx, const int64_t* nsend, const int64_t* const* recv_idx,
+                     const int64_t* nrecv, eqlb_halo_t** handle)
+try
+{
+  if (!handle || nrhs < 1 || nrt < 1 || nentries < 0 || npeers < 0
+      || (npeers > 0 && (!peers || !send_idx || !nsend || !recv_idx || !nrecv)))
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_halo_create: invalid argument");
+  for (int32_t i = 0; i < npeers; ++i)
+  {
+    if (nsend[i] < 0 || nrecv[i] < 0 || nsend[i] > INT32_MAX || nrecv[i] > INT32_MAX || (nsend[i] > 0 && !send_idx[i])
+        || (nrecv[i] > 0 && !recv_idx[i]))
+      return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_halo_create: invalid list of peer entry %d", i);
+    for (int64_t j = 0; j < nsend[i]; ++j)
+      if (send_idx[i][j] < 0 || send_idx[i][j] >= nentries)
+        return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_halo_create: send index %lld of peer entry %d out of range",
+                    (long long)send_idx[i][j], i);
+    for (int64_t j = 0; j < nrecv[i]; ++j)
+      if (recv_idx[i][j] < 0 || recv_idx[i][j] >= nentries)
+        return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_halo_create: receive index %lld of peer entry %d out of range",
+                    (long long)recv_idx[i][j], i);
+  }
+  std::unique_ptr<eqlb_halo, void (*)(eqlb_halo*)> h(new eqlb_halo(), [](eqlb_halo* p) { eqlb_halo_destroy(p); });
+  h->nrhs = nrhs;
+  h->nrt = nrt;
+  h->nentries = nentries;
+  h->npeers = npeers;
+  h->peers.assign(peers, peers + npeers);
+  h->nsend.assign(nsend, nsend + npeers);
+  h->nrecv.assign(nrecv, nrecv + npeers);
+  h->send_idx.assign(npeers, nullptr);
+  h->recv_idx.assign(npeers, nullptr);
+  h->send_buf.assign(npeers, nullptr);
+  h->recv_buf.assign(npeers, nullptr);
+  auto dev = [](void** p, const void* src, size_t bytes) {
+    if (bytes == 0)
+      return true;
+    if (hipMalloc(p, bytes) != hipSuccess)
+      return false;
+    return !src || hipMemcpy(*p, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  for (int32_t i = 0; i < npeers; ++i)
+  {
+    const size_t bs = (size_t)nsend[i] * nrhs * nrt * sizeof(double), br = (size_t)nrecv[i] * nrhs * nrt * sizeof(double);
+    if (!dev(reinterpret_cast<void**>(&h->send_idx[i]), send_idx[i], (size_t)nsend[i] * sizeof(int64_t))
+        || !dev(reinterpret_cast<void**>(&h->recv_idx[i]), recv_idx[i], (size_t)nrecv[i] * sizeof(int64_t))
+        || !dev(reinterpret_cast<void**>(&h->send_buf[i]), nullptr, bs)
+        || !dev(reinterpret_cast<void**>(&h->recv_buf[i]), nullptr, br))
+      return fail(EQLB_ERR_DEVICE, "eqlb_halo_create: device allocation failed");
+  }
+  *handle = h.release();
+  return EQLB_OK;
+}
+catch (const std::bad_alloc&)
+{
+  return fail(EQLB_ERR_NO_MEMORY, "host memory exhausted");
+}
+
+void eqlb_halo_destroy(eqlb_halo_t* h)
+{
+  if (!h)
+    return;
+  for (auto* p : h->send_idx)
+    if (p)
+      (void)hipFree(p);
+  for (auto* p : h->recv_idx)
+    if (p)
+      (void)hipFree(p);
+  for (auto* p : h->send_buf)
+    if (p)
+      (void)hipFree(p);
+  for (auto* p : h->recv_buf)
+    if (p)
+      (void)hipFree(p);
+  delete h;
+}
+
+int eqlb_halo_bytes(const eqlb_halo_t* h, int64_t* bytes_sent, int64_t* bytes_received)
+{
+  if (!h)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_halo_bytes: null handle");
+  int64_t s = 0, r = 0;
+  for (int32_t i = 0; i < h->npeers; ++i)
+  {
+    s += h->nsend[i];
+    r += h->nrecv[i];
+  }
+  if (bytes_sent)
+    *bytes_sent = s * h->nrhs * h->nrt * (int64_t)sizeof(double);
+  if (bytes_received)
+    *bytes_received = r * h->nrhs * h->nrt * (int64_t)sizeof(double);
+  return EQLB_OK;
+}
+
+int eqlb_halo_reduce_plan(eqlb_halo_t* h, void* comm, double* x, void* stream)
+{
+  if (!h || !x)
+    return fail(EQLB_ERR_INVALID_ARGUMENT, "eqlb_halo_reduce_plan: null argument");
+  return eqlb_halo_reduce(comm, h->nrhs, h->nrt, h->nentries, x, h->npeers, h->peers.data(), h->send_idx.data(),
+                          h->nsend.data(), h->send_buf.data(), h->recv_idx.data(), h->nrecv.data(),
+                          h->recv_buf.data(), stream);
 }
 
 } // extern "C"

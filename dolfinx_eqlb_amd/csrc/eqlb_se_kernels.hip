@@ -1658,8 +1658,12 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 }
 
 // one bin per launch (any solver)
+#ifndef EQLB_K4_WAVES
+#define EQLB_K4_WAVES 1 // waves per SIMD asked for the register-solver kernels at k = 4 (1: up to 512 registers)
+#endif
 template <int K, int DEG, int P, int SOLVER, int SCATTER, int MODE = 0>
-__global__ void __launch_bounds__((Sizes<K, DEG, P>::block_of(SOLVER))) k_se_patch(const SeArgs a)
+__global__ void __launch_bounds__((Sizes<K, DEG, P>::block_of(SOLVER)), ((K >= 4 && SOLVER == 1) ? EQLB_K4_WAVES : 1))
+k_se_patch(const SeArgs a)
 {
   extern __shared__ __align__(16) double lds[];
   se_patch_body<K, DEG, P, SOLVER, SCATTER, Sizes<K, DEG, P>::block_of(SOLVER), MODE>(a, blockIdx.x, lds);
@@ -2494,6 +2498,24 @@ static int launch_k4(int P, int solver, int scatter, const SeArgs& a, hipStream_
     if (scatter == EQLB_SCATTER_SLOTS)
       return launch_p<4, 3, 1, 0>(P, a, stream);
     return launch_p<4, 3, 1, 1>(P, a, stream);
+  }
+  if (solver == EQLB_SOLVER_SHUFFLE && mode == 1 && scatter == EQLB_SCATTER_SLOTS)
+  {
+    // constrained-minimisation patch problems (MODE 1 of the body) on the register solver
+    switch (P)
+    {
+    case 4:
+      return launch_t<4, 3, 4, 1, 0, 1>(a, stream);
+    case 8:
+      return launch_t<4, 3, 8, 1, 0, 1>(a, stream);
+    case 16:
+      return launch_t<4, 3, 16, 1, 0, 1>(a, stream);
+    case 32:
+      return launch_t<4, 3, 32, 1, 0, 1>(a, stream);
+    case 64:
+      return launch_t<4, 3, 64, 1, 0, 1>(a, stream);
+    }
+    return EQLB_ERR_UNSUPPORTED;
   }
   if (solver != EQLB_SOLVER_LDS_CHOLESKY || (P != 4 && P != 8))
     return EQLB_ERR_UNSUPPORTED;

@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -641,6 +642,86 @@ void local_solver(std::vector<std::shared_ptr<Function>>& sol, const Form&, cons
     check(eqlb_project_dg(m->h, u->V->degree, bs, 1, nq, qp, qw, qv, out, EQLB_MEM_HOST, g_stream));
   }
 }
+
+// ---- multi-GPU: reverse halo over RCCL through the C ABI (include/eqlb.h: eqlb_halo_*, eqlb_rccl_*) --------------
+// No counterpart in the reference module (its node loop covers the owned nodes of one process,
+// cpp/dolfinx_eqlb/se/reconstruction.hpp:90); this is the C++ host's own multi-GPU path: one process per GPU, a
+// communicator made from a unique id the caller distributes (MPI where DOLFINx runs), one call per sweep.
+struct RcclComm
+{
+  void* comm = nullptr;
+  int nranks = 0, rank = 0;
+  RcclComm(py::bytes unique_id, int nranks_, int rank_) : nranks(nranks_), rank(rank_)
+  {
+    const std::string id = unique_id;
+    if (id.size() != 128)
+      throw std::runtime_error("RcclComm: the unique id has 128 bytes");
+    check(eqlb_rccl_comm_create(id.data(), nranks, rank, &comm));
+  }
+  ~RcclComm() { eqlb_rccl_comm_destroy(comm); }
+  RcclComm(const RcclComm&) = delete;
+  RcclComm& operator=(const RcclComm&) = delete;
+};
+
+struct HaloExchange
+{
+  eqlb_halo_t* h = nullptr;
+  int64_t nentries;
+  int nrhs, width;
+  // send / recv: {peer rank: int64 index array} - rows (of `width` doubles) that leave to / arrive from the peer
+  HaloExchange(int nrhs_, int width_, int64_t nentries_, std::map<int, carray<int64_t>> send,
+               std::map<int, carray<int64_t>> recv)
+      : nentries(nentries_), nrhs(nrhs_), width(width_)
+  {
+    std::vector<int32_t> peers;
+    for (auto& kv : send)
+      peers.push_back(kv.first);
+    for (auto& kv : recv)
+      if (!send.count(kv.first))
+        peers.push_back(kv.first);
+    std::sort(peers.begin(), peers.end());
+    std::vector<const int64_t*> si, ri;
+    std::vector<int64_t> ns, nr;
+    for (int32_t q : peers)
+    {
+      auto s_ = send.find(q);
+      auto r_ = recv.find(q);
+      si.push_back(s_ != send.end() ? s_->second.data() : nullptr);
+      ns.push_back(s_ != send.end() ? (int64_t)s_->second.size() : 0);
+      ri.push_back(r_ != recv.end() ? r_->second.data() : nullptr);
+      nr.push_back(r_ != recv.end() ? (int64_t)r_->second.size() : 0);
+    }
+    check(eqlb_halo_create(nrhs, width, nentries, (int32_t)peers.size(), peers.data(), si.data(), ns.data(),
+                           ri.data(), nr.data(), &h));
+  }
+  ~HaloExchange() { eqlb_halo_destroy(h); }
+  HaloExchange(const HaloExchange&) = delete;
+  HaloExchange& operator=(const HaloExchange&) = delete;
+  void reduce_ptr(RcclComm& c, uintptr_t x)
+  {
+    if (!x)
+      throw std::runtime_error("HaloExchange.reduce: null device pointer");
+    check(eqlb_halo_reduce_plan(h, c.comm, reinterpret_cast<double*>(x), g_stream));
+  }
+  void reduce(RcclComm& c, std::vector<std::shared_ptr<Function>> fs)
+  {
+    // the right-hand sides of one call share a halo: consecutive device blocks of one array
+    if ((int)fs.size() != nrhs || !fs[0] || !fs[0]->on_device)
+      throw std::runtime_error("HaloExchange.reduce: nrhs device-memory Functions (Function.from_device) expected");
+    for (int r = 0; r < nrhs; ++r)
+      if (!fs[r] || !fs[r]->on_device || fs[r]->size() != nentries * width
+          || fs[r]->dev != fs[0]->dev + (uintptr_t)r * nentries * width * sizeof(double))
+        throw std::runtime_error("HaloExchange.reduce: the Functions must be consecutive blocks of one device array");
+    reduce_ptr(c, fs[0]->dev);
+  }
+  py::tuple bytes() const
+  {
+    int64_t s = 0, r = 0;
+    check(eqlb_halo_bytes(h, &s, &r));
+    return py::make_tuple(s, r);
+  }
+};
+
 } // namespace
 
 PYBIND11_MODULE(_cpp, m)
@@ -774,6 +855,24 @@ PYBIND11_MODULE(_cpp, m)
   }, py::arg("degree"), "Gauss rule on [0, 1] used for flux BCs (requires_projection: `quadrature_degree`)");
   m.def("interpolation_quadrature_degree", &interpolation_degree, py::arg("degree_flux"),
         "Degree of the facet rule that stands for the element's interpolation points (no projection)");
+  // ---- multi-GPU (no counterpart in the reference module) ----
+  m.def("rccl_unique_id", []() {
+    char id[128];
+    check(eqlb_rccl_get_unique_id(id));
+    return py::bytes(id, 128);
+  }, "ncclUniqueId (128 bytes) for RcclComm: made on one rank, distributed by the caller");
+  py::class_<RcclComm, std::shared_ptr<RcclComm>>(m, "RcclComm", "RCCL communicator (ncclCommInitRank through the C ABI)")
+      .def(py::init<py::bytes, int, int>(), py::arg("unique_id"), py::arg("nranks"), py::arg("rank"))
+      .def_readonly("nranks", &RcclComm::nranks)
+      .def_readonly("rank", &RcclComm::rank);
+  py::class_<HaloExchange, std::shared_ptr<HaloExchange>>(
+      m, "HaloExchange", "Reverse halo of the node-ownership decomposition: ghost rows -> owner, added there")
+      .def(py::init<int, int, int64_t, std::map<int, carray<int64_t>>, std::map<int, carray<int64_t>>>(),
+           py::arg("nrhs"), py::arg("width"), py::arg("nentries"), py::arg("send"), py::arg("recv"))
+      .def("reduce", &HaloExchange::reduce, py::arg("comm"), py::arg("flux_hdiv"),
+           "pack + clear, grouped ncclSend / ncclRecv, unpack-add on the stream of set_stream")
+      .def("reduce_ptr", &HaloExchange::reduce_ptr, py::arg("comm"), py::arg("device_pointer"))
+      .def("bytes", &HaloExchange::bytes, "(bytes sent, bytes received) per reduction");
   m.def("set_stream", [](uintptr_t s) { g_stream = reinterpret_cast<void*>(s); }, py::arg("stream"),
         "hipStream_t used by calls on device-memory Functions (0: default stream)");
   m.def("device_count", &eqlb_device_count);

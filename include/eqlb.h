@@ -341,6 +341,17 @@ int eqlb_halo_reduce(void* comm, int32_t nrhs, int32_t nrt, int64_t nentries, do
                      const int32_t* peers, const int64_t* const* send_idx, const int64_t* nsend,
                      double* const* send_buf, const int64_t* const* recv_idx, const int64_t* nrecv,
                      double* const* recv_buf, void* stream);
+/* A halo plan keeps the index lists on the device and owns the staging buffers (what a C++ host would otherwise
+ * allocate itself): send_idx[i] / recv_idx[i] are HOST arrays here, copied once.
+ *   eqlb_halo_reduce_plan  = eqlb_halo_reduce with the plan's lists and buffers
+ *   eqlb_halo_bytes        bytes sent / received by this rank per reduction */
+typedef struct eqlb_halo eqlb_halo_t;
+int eqlb_halo_create(int32_t nrhs, int32_t nrt, int64_t nentries, int32_t npeers, const int32_t* peers,
+                     const int64_t* const* send_idx, const int64_t* nsend, const int64_t* const* recv_idx,
+                     const int64_t* nrecv, eqlb_halo_t** handle);
+void eqlb_halo_destroy(eqlb_halo_t* handle);
+int eqlb_halo_bytes(const eqlb_halo_t* handle, int64_t* bytes_sent, int64_t* bytes_received);
+int eqlb_halo_reduce_plan(eqlb_halo_t* handle, void* comm, double* x, void* stream);
 int eqlb_rccl_get_unique_id(void* id128);
 int eqlb_rccl_comm_create(const void* id128, int32_t nranks, int32_t rank, void** comm);
 void eqlb_rccl_comm_destroy(void* comm);

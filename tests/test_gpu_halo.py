@@ -304,3 +304,29 @@ def test_rccl_transport_argument_checks():
         cpp.RcclComm(b"short", 1, 0)
     rc = cpp.lib().eqlb_halo_exchange(None, C.c_int32(0), None, None, None, None, None, None)
     assert rc != 0 and b"eqlb_halo_exchange" in cpp.lib().eqlb_last_error()
+
+
+def test_pybind_halo_exchange_self_send():
+    """The same self-send through the pybind11 module (the C++ host's classes RcclComm / HaloExchange over
+    eqlb_halo_create / eqlb_halo_reduce_plan): index lists as host arrays, buffers owned by the library."""
+    import torch
+    from dolfinx_eqlb_amd import _cpp
+    dev = torch.device("cuda", 0)
+    nrhs, nent, nrt = 2, 600, 15
+    rng = np.random.default_rng(7)
+    perm = rng.permutation(nent)
+    A, B = np.sort(perm[:90]).astype(np.int64), np.sort(perm[90:180]).astype(np.int64)
+    comm = _cpp.RcclComm(_cpp.rccl_unique_id(), 1, 0)
+    halo = _cpp.HaloExchange(nrhs, nrt, nent, {0: A}, {0: B})
+    assert halo.bytes() == (8 * nrhs * nrt * A.size, 8 * nrhs * nrt * B.size)
+    x0 = rng.standard_normal((nrhs, nent, nrt))
+    x = torch.from_numpy(x0.ravel().copy()).to(dev)
+    _cpp.set_stream(torch.cuda.current_stream().cuda_stream)
+    halo.reduce_ptr(comm, x.data_ptr())
+    torch.cuda.synchronize()
+    expect = x0.copy()
+    expect[:, B] += x0[:, A]
+    expect[:, A] = 0.0
+    assert np.array_equal(x.cpu().numpy().reshape(nrhs, nent, nrt), expect)
+    with pytest.raises(RuntimeError, match="out of range"):
+        _cpp.HaloExchange(1, 3, 10, {0: np.array([11], dtype=np.int64)}, {})
