@@ -99,6 +99,12 @@ int fill_tables_host(int k, int deg, std::vector<double>& out)
   return (out.size() == table_doubles(k, deg)) ? 0 : EQLB_ERR_UNSUPPORTED;
 }
 
+#ifndef EQLB_EV_FMA
+#define EQLB_EV_FMA 1
+#endif
+#ifndef EQLB_LE_FMA
+#define EQLB_LE_FMA 1
+#endif
 #ifndef EQLB_P2_DIV_NODAL
 #define EQLB_P2_DIV_NODAL 1 // P2 data: divergence of the projected flux through its nodal values instead of the tensor D
 #endif
@@ -332,17 +338,29 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
             const double jt0 = J00 * g2.x + J10 * g2.y, jt1 = J01 * g2.x + J11 * g2.y; // J^T G_i
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
+#if EQLB_EV_FMA
               Rq[q] = __builtin_fma(gg, sHG[i * NQ + q], __builtin_fma(fd, tH[i * NQ + q], Rq[q]));
+#else
+              Rq[q] += fd * tH[i * NQ + q] + gg * sHG[i * NQ + q];
+#endif
 #pragma unroll
             for (int h = 0; h < NH; ++h)
             {
               if constexpr (AL)
               {
                 const double2 w2 = reinterpret_cast<const double2*>(wg)[h * ND + i];
+#if EQLB_EV_FMA
                 LeG[h] = __builtin_fma(w2.y, jt1, __builtin_fma(w2.x, jt0, LeG[h]));
+#else
+                LeG[h] += w2.x * jt0 + w2.y * jt1;
+#endif
               }
               else
+#if EQLB_EV_FMA
                 LeG[h] = __builtin_fma(wg[(h * ND + i) * 2 + 1], jt1, __builtin_fma(wg[(h * ND + i) * 2], jt0, LeG[h]));
+#else
+                LeG[h] += wg[(h * ND + i) * 2] * jt0 + wg[(h * ND + i) * 2 + 1] * jt1;
+#endif
             }
           }
         }
@@ -679,9 +697,15 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
             const double2 w2 = reinterpret_cast<const double2*>(wq + (2 * NH + h) * NCOLS)[c2];
             const double f0 = full[2 * c2], f1 = (2 * c2 + 1 < NCOL) ? full[2 * c2 + 1] : 0.0; // pad column
             // (two fused multiply-adds per sum: "s += a * b + c * d" compiles to mul + fma + add)
+#if EQLB_LE_FMA
             s0 = __builtin_fma(w0.y, f1, __builtin_fma(w0.x, f0, s0));
             s1 = __builtin_fma(w1.y, f1, __builtin_fma(w1.x, f0, s1));
             s2 = __builtin_fma(w2.y, f1, __builtin_fma(w2.x, f0, s2));
+#else
+            s0 += w0.x * f0 + w0.y * f1;
+            s1 += w1.x * f0 + w1.y * f1;
+            s2 += w2.x * f0 + w2.y * f1;
+#endif
           }
         }
         else
@@ -1294,6 +1318,8 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
             I11 = D00 * id;
             I01 = -D01 * id;
           };
+  #define FNMA4(a0, b0, a1, b1, a2, b2, a3, b3, x)                                                    \
+    __builtin_fma(-(a3), (b3), __builtin_fma(-(a2), (b2), __builtin_fma(-(a1), (b1), __builtin_fma(-(a0), (b0), (x)))))
   #define EQLB_BPCR_LEVEL(S)                                                                          \
     if constexpr (P > S)                                                                              \
     {                                                                                                 \
@@ -1324,13 +1350,14 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         ga[aa][0] = Ah[0][aa] * h00 + Ah[1][aa] * h01;                                                \
         ga[aa][1] = Ah[0][aa] * h01 + Ah[1][aa] * h11;                                                \
       }                                                                                               \
-      D00 -= al[0][0] * A[0][0] + al[0][1] * A[0][1] + ga[0][0] * Ah[0][0] + ga[0][1] * Ah[1][0];     \
-      D01 -= al[0][0] * A[1][0] + al[0][1] * A[1][1] + ga[0][0] * Ah[0][1] + ga[0][1] * Ah[1][1];     \
-      D11 -= al[1][0] * A[1][0] + al[1][1] * A[1][1] + ga[1][0] * Ah[0][1] + ga[1][1] * Ah[1][1];     \
+      /* (chains of fused multiply-adds: "x -= a * b + c * d + ..." costs one instruction more) */  \
+      D00 = FNMA4(al[0][0], A[0][0], al[0][1], A[0][1], ga[0][0], Ah[0][0], ga[0][1], Ah[1][0], D00); \
+      D01 = FNMA4(al[0][0], A[1][0], al[0][1], A[1][1], ga[0][0], Ah[0][1], ga[0][1], Ah[1][1], D01); \
+      D11 = FNMA4(al[1][0], A[1][0], al[1][1], A[1][1], ga[1][0], Ah[0][1], ga[1][1], Ah[1][1], D11); \
       _Pragma("unroll") for (int aa = 0; aa < KB; ++aa)                                               \
       {                                                                                               \
         _Pragma("unroll") for (int c = 0; c < 1 + W; ++c)                                             \
-          R[aa][c] -= al[aa][0] * Rl[0][c] + al[aa][1] * Rl[1][c] + ga[aa][0] * Rh[0][c] + ga[aa][1] * Rh[1][c]; \
+          R[aa][c] = FNMA4(al[aa][0], Rl[0][c], al[aa][1], Rl[1][c], ga[aa][0], Rh[0][c], ga[aa][1], Rh[1][c], R[aa][c]); \
         const double n0 = -(al[aa][0] * Al[0][0] + al[aa][1] * Al[1][0]);                             \
         const double n1 = -(al[aa][0] * Al[0][1] + al[aa][1] * Al[1][1]);                             \
         A[aa][0] = n0;                                                                                \
@@ -1342,6 +1369,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
           EQLB_BPCR_LEVEL(4)
           EQLB_BPCR_LEVEL(8)
   #undef EQLB_BPCR_LEVEL
+  #undef FNMA4
           invert();
           if (!posdef && pvalid)
             status_local = 1;
@@ -2103,48 +2131,54 @@ __device__ __forceinline__ void tile_sweep_flush(const SeArgs& a0, const TileArg
       const int32_t cell = cells[cl];
       if (cell < 0)
         continue;
-      double c[NRT], y[NRT];
+      double c[NRT];
 #pragma unroll
       for (int i = 0; i < NRT; ++i)
         c[i] = packed_sum<K, NPK>(sSlots + (int64_t)cl * 3 * NPK, i);
-#pragma unroll
-      for (int i = 0; i < NRT; ++i)
-      {
+      // rows of C are fetched per output row inside ROLLED loops: unrolled, the compiler hoists the whole matrix
+      // (k(k+2)^2 doubles) out of the cell loop and the kernel pays for the scratch it then needs on EVERY path
+      auto row = [&](const int i) {
+        const double* Ci = ta.basis_C + (int64_t)i * NRT;
         double s_ = 0.0;
 #pragma unroll
         for (int j = 0; j < NRT; ++j)
-          s_ += ta.basis_C[i * NRT + j] * c[j];
-        y[i] = s_;
-      }
-#pragma unroll
+          s_ = __builtin_fma(Ci[j], c[j], s_);
+        return s_;
+      };
+#pragma unroll 1
       for (int lf = 0; lf < 3; ++lf)
       {
         const int32_t code = own[cl * 3 + lf];
         if (code < 0)
           continue;
         const bool rev = (code & 1) != 0 && ta.basis_R != nullptr;
+        double yf[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+          yf[j] = row(lf * K + j);
 #pragma unroll
         for (int j = 0; j < K; ++j)
         {
-          double g = y[lf * K + j];
+          double g = yf[j];
           if (rev)
           {
             g = 0.0;
 #pragma unroll
             for (int i = 0; i < K; ++i)
-              g += ta.basis_R[j * K + i] * y[lf * K + i];
+              g += ta.basis_R[j * K + i] * yf[i];
           }
           const int64_t dof = ta.cell_dofs ? (int64_t)ta.cell_dofs[(int64_t)cell * NRT + lf * K + j]
                                            : (int64_t)(code >> 1) * K + j;
           xc[dof] = ta.accumulate ? xc[dof] + g : g;
         }
       }
-#pragma unroll
+#pragma unroll 1
       for (int i = 0; i < NI; ++i)
       {
+        const double yi = row(3 * K + i);
         const int64_t dof = ta.cell_dofs ? (int64_t)ta.cell_dofs[(int64_t)cell * NRT + 3 * K + i]
                                          : (int64_t)ta.nfacets * K + (int64_t)cell * NI + i;
-        xc[dof] = ta.accumulate ? xc[dof] + y[3 * K + i] : y[3 * K + i];
+        xc[dof] = ta.accumulate ? xc[dof] + yi : yi;
       }
     }
     return;

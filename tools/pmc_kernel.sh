@@ -8,7 +8,7 @@ rm -rf "$OUT" && mkdir -p "$OUT"
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d "$OUT/p$i" -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" > "$OUT/log$i.txt" 2>&1 || echo "pass $i failed"
+  rocprofv3 --pmc $set --output-format csv -d "$OUT/p$i" -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 --settle 0 --windows 1 "$@" > "$OUT/log$i.txt" 2>&1 || echo "pass $i failed"
 done
 python3 - "$K" "$OUT" "$*" <<'PY'
 import collections, csv, glob, sys
