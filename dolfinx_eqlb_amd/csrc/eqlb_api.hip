@@ -100,6 +100,8 @@ void free_boundary(eqlb_se* h)
   dfree(h->node_group);
   dfree(h->node_wslevel);
   h->ws_levels = 1;
+  dfree(h->rest_cells);
+  h->nrest_cells = 0;
   dfree(h->bvals);
   dfree(h->node_slot);
   dfree(h->node_patch);
@@ -527,19 +529,48 @@ void parallel_for(int64_t n, int64_t min_chunk, F f)
 
 // Tiled SoA of the plain flux equilibration (EQLB_SCATTER_TILED): cells bisected recursively by
 // their centroids into tiles of TC cells; a tile lists every (masked-in) node of its cells.
-int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::BuildArgs a, int tc_fixed = 0, int max_bin = eqlb::MAX_BINS)
+int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::BuildArgs a, int tc_fixed = 0, int max_bin = eqlb::MAX_BINS,
+                bool full_only = false)
 {
-  // nodes of bins >= max_bin are left out (like masked-out nodes): another path equilibrates them
+  // nodes of bins >= max_bin are left out (like masked-out nodes): another path equilibrates them.
+  // full_only (fused stress launch): so are all patches that are not FULL (interior, as many cells as lanes);
+  // the lists of a tile are padded to whole wave-blocks with copies of a full patch that own no cell
+  const eqlb::DeviceMesh& m = h->mesh->m;
+  const int32_t nc = m.ncells;
   std::vector<int8_t> node_bin(node_bin_all);
   h->t_rest = 0;
-  for (auto& b : node_bin)
-    if (b >= max_bin)
+  for (int32_t i = 0; i < m.nnodes; ++i)
+  {
+    int8_t& b = node_bin[i];
+    if (b < 0)
+      continue;
+    const bool full = m.h_node_ncells[i] == m.h_node_nfcts[i] && m.h_node_ncells[i] == eqlb::BIN_P[b];
+    if (b >= max_bin || (full_only && !full))
     {
       b = -1;
       ++h->t_rest;
     }
-  const eqlb::DeviceMesh& m = h->mesh->m;
-  const int32_t nc = m.ncells;
+  }
+  dfree(h->rest_cells);
+  h->nrest_cells = 0;
+  if (full_only && h->t_rest > 0)
+  {
+    // cells with a vertex whose patch the generic kernels take: the compact reduction of their slot rows
+    std::vector<int32_t> rc;
+    for (int32_t c = 0; c < nc; ++c)
+      for (int j = 0; j < 3; ++j)
+      {
+        const int32_t nd = m.h_cell_nodes[3 * (size_t)c + j];
+        if (node_bin_all[nd] >= 0 && node_bin[nd] < 0)
+        {
+          rc.push_back(c);
+          break;
+        }
+      }
+    h->nrest_cells = (int64_t)rc.size();
+    if (upload(&h->rest_cells, rc.data(), std::max<size_t>(rc.size(), 1)))
+      return EQLB_ERR_DEVICE;
+  }
   // Tile size: the default, or - on meshes that fill the chip several times over - the size that
   // makes the tiles fill whole rounds of the 512 workgroup slots (2 per CU): 1M triangles in 2 045
   // tiles of 489 cells run in 4 rounds, 2 084 tiles of 480 cells leave 36 tiles for a fifth
@@ -726,6 +757,14 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
         tiles[t].nfull[b_] = cnt[3 * b_];
         tiles[t].nint[b_] = cnt[3 * b_] + cnt[3 * b_ + 1];
         tiles[t].npatch[b_] = cnt[3 * b_] + cnt[3 * b_ + 1] + cnt[3 * b_ + 2];
+        if (full_only)
+        {
+          // whole wave-blocks: nint keeps the number of real patches, the others are copies (pass 2)
+          const int per = 64 / eqlb::BIN_P[b_];
+          const int padded = (per > 0) ? (cnt[3 * b_] + per - 1) / per * per : cnt[3 * b_];
+          tiles[t].nfull[b_] = padded;
+          tiles[t].npatch[b_] = padded;
+        }
       }
     }
   });
@@ -750,11 +789,13 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
       for (int b_ = 0; b_ < NB; ++b_)
       {
         int32_t slot = tiles[t].slot_start[b_];
+        const int32_t nreal = full_only ? tiles[t].nint[b_] : tiles[t].npatch[b_];
         for (int32_t i = 0, p_ = tiles[t].patch_start[b_]; i < tiles[t].npatch[b_]; ++i, ++p_, slot += eqlb::BIN_P[b_])
         {
-          inst_node[p_] = *src++;
+          // (padding copy: the last real patch once more, tile -1 = it owns no cell and stores nothing)
+          inst_node[p_] = (i < nreal) ? *src++ : src[-1];
           inst_slot[p_] = slot;
-          inst_tile[p_] = (int32_t)t;
+          inst_tile[p_] = (i < nreal) ? (int32_t)t : -1;
         }
       }
     }
@@ -1154,14 +1195,28 @@ try
   }
   h->nslots = slot_off;
   h->npatch_total = patch_off;
-  for (int32_t i = 0; i < m.nnodes; ++i)
-  {
+  // fused stress launch (RT_2, no flux BCs on the stress rows): it takes the FULL patches of the bins 0, 1 -
+  // interior, as many cells as lanes -, listed first in their bin; the generic kernels take the patches behind them
+  const bool full_first = h->stress && h->k == 2 && !h->stress_flux_bcs && h->mode == 0;
+  auto is_full = [&](int32_t i) {
     const int b = node_bin[i];
-    if (b < 0)
-      continue;
-    node_patch[i] = h->bins[b].patch_offset + count[b];
-    node_slot[i] = h->bins[b].slot_offset + count[b] * eqlb::BIN_P[b];
-    ++count[b];
+    return full_first && b >= 0 && b < 2 && m.h_node_ncells[i] == m.h_node_nfcts[i]
+           && m.h_node_ncells[i] == eqlb::BIN_P[b];
+  };
+  for (int pass = 0; pass < 2; ++pass)
+  {
+    for (int32_t i = 0; i < m.nnodes; ++i)
+    {
+      const int b = node_bin[i];
+      if (b < 0 || is_full(i) != (pass == 0))
+        continue;
+      node_patch[i] = h->bins[b].patch_offset + count[b];
+      node_slot[i] = h->bins[b].slot_offset + count[b] * eqlb::BIN_P[b];
+      ++count[b];
+    }
+    if (pass == 0)
+      for (int b = 0; b < eqlb::MAX_BINS; ++b)
+        h->bins[b].nfull = count[b];
   }
 
   tm.lap("binning");
@@ -1229,7 +1284,7 @@ try
   if (h->t_stress || (!h->stress && h->k <= 3))
   {
     // fused stress launch: its own tile size, patches of up to 8 facets (bins 0, 1)
-    const int stt = h->t_stress ? build_tiles(h, node_bin, a, eqlb::stress_tile_cells(), 2) : build_tiles(h, node_bin, a);
+    const int stt = h->t_stress ? build_tiles(h, node_bin, a, eqlb::stress_tile_cells(), 2, true) : build_tiles(h, node_bin, a);
     if (stt)
       return stt;
     if (h->mode == 1)
@@ -1528,7 +1583,20 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
   // ---- slot path: (cell, vertex) rows into the slot buffer, weak symmetry on the slot rows, reduction.
   // first_bin > 0: only the patches of the bins >= first_bin (the rest of a fused stress launch);
   // their sums are ADDED to what the tiled launch wrote ----
+  // first_bin = -1: the REST of a fused stress launch - in the bins 0, 1 the patches behind the full ones
+  // (Bin::nfull), the higher bins entirely; sums added by the compact reduction over the cells they touch
   auto run_slot_path = [&](int first_bin, int accumulate) -> int {
+    const bool rest = first_bin < 0;
+    auto bin_np = [&](int b) -> int64_t {
+      if (rest)
+        return h->bins[b].npatch - ((b < 2) ? h->bins[b].nfull : 0);
+      return (b >= first_bin) ? h->bins[b].npatch : 0;
+    };
+    auto bin_po = [&](int b) -> int64_t { return h->bins[b].patch_offset + ((rest && b < 2) ? h->bins[b].nfull : 0); };
+    auto bin_so = [&](int b) -> int64_t {
+      return h->bins[b].slot_offset + ((rest && b < 2) ? h->bins[b].nfull * h->bins[b].P : 0);
+    };
+    const int cover = rest ? 1 : first_bin; // 0: every patch writes its slot rows
     if (!h->slots)
     {
       if (upload<double>(&h->slots, nullptr, n_slot * 3))
@@ -1540,9 +1608,9 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
     // The reduction adds ALL slot rows of a cell.  A run over the bins >= first_bin rewrites only their rows: rows
     // of the lower bins left by an earlier run over more bins (option "scatter" / "solver" changed on this handle)
     // would be added again on top of what the tiled launch wrote
-    if (h->slots_first_bin < first_bin)
+    if (h->slots_first_bin < cover)
       HIP_TRY(hipMemsetAsync(h->slots, 0, n_slot * 3 * sizeof(double), stream));
-    h->slots_first_bin = first_bin;
+    h->slots_first_bin = cover;
     eqlb::SeArgs as = a;
     if ((h->mode == 1 && h->k <= 3) || (h->fused && h->solver == EQLB_SOLVER_SHUFFLE && h->k <= 3))
     {
@@ -1552,9 +1620,9 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
       for (int b = 0; b < eqlb::MAX_BINS; ++b)
       {
         fb.block_start[b] = nb;
-        fb.npatch[b] = (b >= first_bin) ? h->bins[b].npatch : 0;
-        fb.slot_offset[b] = h->bins[b].slot_offset;
-        fb.patch_offset[b] = h->bins[b].patch_offset;
+        fb.npatch[b] = bin_np(b);
+        fb.slot_offset[b] = bin_so(b);
+        fb.patch_offset[b] = bin_po(b);
         nb += (fb.npatch[b] * h->bins[b].P + 255) / 256;
       }
       fb.block_start[eqlb::MAX_BINS] = nb;
@@ -1572,13 +1640,13 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
         HIP_TRY(hipEventRecord(evs[1], stream));
     }
     else
-      for (int b = first_bin; b < eqlb::MAX_BINS; ++b)
+      for (int b = 0; b < eqlb::MAX_BINS; ++b)
       {
-        if (h->bins[b].npatch == 0)
+        if (bin_np(b) == 0)
           continue;
-        as.npatch = h->bins[b].npatch;
-        as.slot_offset = h->bins[b].slot_offset;
-        as.patch_offset = h->bins[b].patch_offset;
+        as.npatch = bin_np(b);
+        as.slot_offset = bin_so(b);
+        as.patch_offset = bin_po(b);
         if (evs && first_bin == 0)
           HIP_TRY(hipEventRecord(evs[2 * b], stream));
         for (int r = 0; r < h->nrhs; ++r)
@@ -1601,13 +1669,13 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
       select_rhs(as, 0, true); // the kernel works on the slot rows of RHS 0 and 1
       // (overlapping groups of boundary patches: one pass per level, a pass skips the patches of other levels)
       for (int lv = 0; lv < h->ws_levels; ++lv)
-        for (int b = first_bin; b < eqlb::MAX_BINS; ++b)
+        for (int b = 0; b < eqlb::MAX_BINS; ++b)
         {
-          if (h->bins[b].npatch == 0)
+          if (bin_np(b) == 0)
             continue;
-          as.npatch = h->bins[b].npatch;
-          as.slot_offset = h->bins[b].slot_offset;
-          as.patch_offset = h->bins[b].patch_offset;
+          as.npatch = bin_np(b);
+          as.slot_offset = bin_so(b);
+          as.patch_offset = bin_po(b);
           as.ws_level = lv;
           const int st = eqlb::launch_se_weaksym(h->k, h->bins[b].P, !h->stress_flux_bcs, as, stream);
           if (st)
@@ -1623,6 +1691,15 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
     for (int r = 1; r < h->nrhs; ++r)
       contiguous = contiguous && d_x[r] == d_x[0] + r * s_x;
     const int nlaunch = contiguous ? 1 : h->nrhs, per = contiguous ? h->nrhs : 1;
+    if (rest)
+    {
+      // only the cells that a patch of the generic kernels touches (the slot rows of their other vertices are zero)
+      for (int r = 0; r < h->nrhs; ++r)
+        if (eqlb::launch_reduce_slots_cells(h->nrt, m.ncells, h->nrest_cells, h->rest_cells,
+                                            h->slots + (size_t)r * s_slot * 3, d_x[r], stream))
+          return fail(EQLB_ERR_UNSUPPORTED, "compact slot reduction for %d DOFs per cell is not in this build", h->nrt);
+      return EQLB_OK;
+    }
     for (int l = 0; l < nlaunch; ++l)
     {
       const double* sl = h->slots + (size_t)l * s_slot * 3;
@@ -1705,7 +1782,7 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
     {
       hipEvent_t* keep = evs;
       evs = nullptr;
-      const int st = run_slot_path(2, 1);
+      const int st = run_slot_path(-1, 1);
       evs = keep;
       if (st)
         return st;

@@ -64,6 +64,8 @@ struct Bin
   int64_t npatch = 0;
   int64_t slot_offset = 0;   // into slot arrays
   int64_t patch_offset = 0;  // into patch arrays
+  int64_t nfull = 0;         // fused stress tiles: the leading patches of the bin are the FULL ones (interior, as many
+                             // cells as lanes) that the fused kernel takes; the slot path takes [nfull, npatch)
 };
 
 // kernel arguments of the patch kernel (one launch per bin)
@@ -206,6 +208,8 @@ void launch_ev_reduce(const DeviceMesh& m, int k, int nrhs, const int32_t* cell_
                       hipStream_t stream);
 int launch_reduce_slots(int nrt, int32_t ncells, int32_t nrhs, const double* slots, double* x, int accumulate,
                         hipStream_t stream);
+int launch_reduce_slots_cells(int nrt, int32_t ncells, int64_t nlist, const int32_t* cells, const double* slots,
+                              double* x, hipStream_t stream);
 int projection_matrix_host(int degree, int nq, const double* pts, const double* wts,
                            std::vector<double>& Pm);
 void launch_project_dg(int64_t ncells, int nd, int nq, int bs, const double* Pm, const double* qv,
@@ -286,7 +290,9 @@ struct eqlb_se
   // tiled SoA (plain SE, EQLB_SCATTER_TILED)
   int32_t ntiles = 0, tile_tc = 0;
   bool t_stress = false;            // the tiles serve the fused stress launch (bins P <= 8 only)
-  int64_t t_rest = 0;               // patches left to the generic kernels (bins P >= 16) when t_stress
+  int64_t t_rest = 0;               // patches left to the generic kernels when t_stress (everything but full patches)
+  int32_t* rest_cells = nullptr;    // cells with a vertex whose patch runs on the generic kernels (compact reduction)
+  int64_t nrest_cells = 0;
   int64_t t_nslots = 0, t_npatch = 0;
   eqlb::TileDesc* t_tiles = nullptr;
   int32_t *t_tile_cells = nullptr, *t_slot_cell = nullptr, *t_facet_owner = nullptr;

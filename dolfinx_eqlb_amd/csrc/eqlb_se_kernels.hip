@@ -2418,6 +2418,38 @@ int launch_reduce_slots(int nrt, int32_t ncells, int32_t nrhs, const double* slo
   return 0;
 }
 
+// the same for a LIST of cells, always adding (the rest of a fused stress launch: the few cells that have a vertex
+// whose patch ran on the generic kernels; the slot rows of the other vertices are zero)
+template <int NRT>
+__global__ void __launch_bounds__(256)
+k_reduce_slots_cells(int64_t ntotal, const int32_t* __restrict__ cells, const double* __restrict__ slots,
+                     double* __restrict__ x)
+{
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ntotal)
+    return;
+  const int64_t c = cells[e / NRT];
+  const int i = (int)(e % NRT);
+  const double* s = slots + c * 3 * NRT + i;
+  x[c * NRT + i] += (s[0] + s[NRT]) + s[2 * NRT];
+}
+
+int launch_reduce_slots_cells(int nrt, int32_t ncells, int64_t nlist, const int32_t* cells, const double* slots,
+                              double* x, hipStream_t stream)
+{
+  (void)ncells;
+  const int64_t ntotal = nlist * nrt;
+  if (ntotal == 0)
+    return 0;
+  const int block = 256;
+  const int64_t grid = (ntotal + block - 1) / block;
+  if (nrt == 8)
+    hipLaunchKernelGGL(k_reduce_slots_cells<8>, dim3(grid), dim3(block), 0, stream, ntotal, cells, slots, x);
+  else
+    return EQLB_ERR_UNSUPPORTED;
+  return 0;
+}
+
 // ---- dispatch -------------------------------------------------------------------------------------
 template <int K, int DEG, int P, int SOLVER, int SCATTER, int MODE = 0>
 static int launch_t(const SeArgs& a, hipStream_t stream)

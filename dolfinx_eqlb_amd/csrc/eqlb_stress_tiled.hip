@@ -6,9 +6,16 @@
 // buffer, no separate weak-symmetry pass, no reduction pass.
 //
 // Applies to the case without flux boundary conditions on the stress rows (pure primal Dirichlet
-// data: the benchmark and the reference's convergence tests) and patches of up to 8 facets; the other
-// patches of a mesh (larger valence) and meshes with stress flux BCs run on the generic kernels of
-// eqlb_se_weaksym.hip.
+// data: the benchmark and the reference's convergence tests) and to the FULL patches of a mesh -
+// interior, 4 or 8 cells = as many cells as lanes of their group: on them the patch shape is a
+// compile-time constant and the body needs 244 registers, no scratch.  Every other patch (boundary
+// patches, interior patches of 3, 5, 6, 7 or more than 8 cells) and meshes with stress flux BCs run on
+// the generic kernels (row sweeps into the slot buffer, eqlb_se_weaksym.hip, compact reduction over the
+// cells they touch) in the same call.  Round 2 also ran a generic instance of this body inside this
+// kernel: it needs 40 registers more than exist, and the scratch memory a kernel reserves for its worst
+// instance slows EVERY wave of it (measured on the EV kernels in round 3: 332 B of scratch per lane,
+// never touched on the benchmark's path, cost 27 %).  The tile lists are padded to whole wave-blocks
+// with copies of a full patch that own no cell (they compute and store nothing).
 //
 // Weak symmetry in lane-parallel form (tests/proto_stress_lanes.py is the numpy statement): lane i of
 // a patch group <-> cell T_{i+1} <-> facet row E_i <-> ring point i (the outer node of E_i).
@@ -895,18 +902,17 @@ k_se_stress_tiled(const SeArgs a0, const TileArgs ta, const StressRows rows)
   SeArgs a = a0;
 #define EQLB_STRESS_BIN(B, PP)                                                                      \
   {                                                                                                 \
+    /* only FULL patches are listed (interior, PP cells), padded to whole wave-blocks with copies that own \
+       no cell: the generic instance of the body (boundary patches, fewer cells than lanes) needs 40 \
+       registers more than there are and the scratch it brings slows every wave of the kernel; those \
+       patches run on the generic kernels (slot path) in the same call */                           \
     const int np = td.npatch[B];                                                                    \
-    const int nwb = (np * PP + 63) >> 6;                                                            \
+    const int nwb = (np * PP) >> 6;                                                                 \
     a.npatch = np;                                                                                  \
     a.slot_offset = td.slot_start[B];                                                               \
     a.patch_offset = td.patch_start[B];                                                             \
-    const int nwb_full = (td.nfull[B] * PP) >> 6;                                                   \
-    /* two loops, not one loop with a branch: the register allocation of the full-patch instance (no spills \
-       on its own) is then not tied to the generic one (same wave-block -> wave assignment) */         \
-    for (; u < nwb_full; u += NW)                                                                   \
-      stress_patch_body<PP, true>(a, rows, lds, (int64_t)u * 64 + lane, sSlots, TC);                \
     for (; u < nwb; u += NW)                                                                        \
-      stress_patch_body<PP, false>(a, rows, lds, (int64_t)u * 64 + lane, sSlots, TC);               \
+      stress_patch_body<PP, true>(a, rows, lds, (int64_t)u * 64 + lane, sSlots, TC);                \
     u -= nwb;                                                                                       \
   }
   EQLB_STRESS_BIN(0, 4)
