@@ -1065,6 +1065,12 @@ void eqlb_se_destroy(eqlb_se_t* h)
         (void)hipEventDestroy(h->ev[i]);
     delete[] h->ev;
   }
+  if (h->ev_fork)
+    (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join)
+    (void)hipEventDestroy(h->ev_join);
+  if (h->side_stream)
+    (void)hipStreamDestroy(h->side_stream);
   delete h;
 }
 
@@ -1585,6 +1591,10 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
   // their sums are ADDED to what the tiled launch wrote ----
   // first_bin = -1: the REST of a fused stress launch - in the bins 0, 1 the patches behind the full ones
   // (Bin::nfull), the higher bins entirely; sums added by the compact reduction over the cells they touch
+  // sp_stream / sp_phase: stream of the launches; phase 0 everything, 1 the patch kernels only, 2 the reduction only
+  // (the rest of a fused stress launch runs its patch kernels on a side stream next to the fused kernel)
+  hipStream_t sp_stream = stream;
+  int sp_phase = 0;
   auto run_slot_path = [&](int first_bin, int accumulate) -> int {
     const bool rest = first_bin < 0;
     auto bin_np = [&](int b) -> int64_t {
@@ -1597,6 +1607,14 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
       return h->bins[b].slot_offset + ((rest && b < 2) ? h->bins[b].nfull * h->bins[b].P : 0);
     };
     const int cover = rest ? 1 : first_bin; // 0: every patch writes its slot rows
+    if (sp_phase == 2)
+    {
+      for (int r = 0; r < h->nrhs; ++r)
+        if (eqlb::launch_reduce_slots_cells(h->nrt, m.ncells, h->nrest_cells, h->rest_cells,
+                                            h->slots + (size_t)r * s_slot * 3, d_x[r], sp_stream))
+          return fail(EQLB_ERR_UNSUPPORTED, "compact slot reduction for %d DOFs per cell is not in this build", h->nrt);
+      return EQLB_OK;
+    }
     if (!h->slots)
     {
       if (upload<double>(&h->slots, nullptr, n_slot * 3))
@@ -1609,7 +1627,7 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
     // of the lower bins left by an earlier run over more bins (option "scatter" / "solver" changed on this handle)
     // would be added again on top of what the tiled launch wrote
     if (h->slots_first_bin < cover)
-      HIP_TRY(hipMemsetAsync(h->slots, 0, n_slot * 3 * sizeof(double), stream));
+      HIP_TRY(hipMemsetAsync(h->slots, 0, n_slot * 3 * sizeof(double), sp_stream));
     h->slots_first_bin = cover;
     eqlb::SeArgs as = a;
     if ((h->mode == 1 && h->k <= 3) || (h->fused && h->solver == EQLB_SOLVER_SHUFFLE && h->k <= 3))
@@ -1630,14 +1648,14 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
       {
         select_rhs(as, r, true);
         if (evs && r == 0 && first_bin == 0)
-          HIP_TRY(hipEventRecord(evs[0], stream));
-        const int st = (h->mode == 1) ? eqlb::launch_ev_patch_fused(h->k, as, fb, stream)
-                                      : eqlb::launch_se_patch_fused(h->k, h->deg, EQLB_SCATTER_SLOTS, as, fb, stream);
+          HIP_TRY(hipEventRecord(evs[0], sp_stream));
+        const int st = (h->mode == 1) ? eqlb::launch_ev_patch_fused(h->k, as, fb, sp_stream)
+                                      : eqlb::launch_se_patch_fused(h->k, h->deg, EQLB_SCATTER_SLOTS, as, fb, sp_stream);
         if (st)
           return fail(st, "fused patch kernel launch failed (k=%d)", h->k);
       }
       if (evs && first_bin == 0)
-        HIP_TRY(hipEventRecord(evs[1], stream));
+        HIP_TRY(hipEventRecord(evs[1], sp_stream));
     }
     else
       for (int b = 0; b < eqlb::MAX_BINS; ++b)
@@ -1648,16 +1666,16 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
         as.slot_offset = bin_so(b);
         as.patch_offset = bin_po(b);
         if (evs && first_bin == 0)
-          HIP_TRY(hipEventRecord(evs[2 * b], stream));
+          HIP_TRY(hipEventRecord(evs[2 * b], sp_stream));
         for (int r = 0; r < h->nrhs; ++r)
         {
           select_rhs(as, r, true);
-          const int st = eqlb::launch_se_patch(h->k, h->deg, h->bins[b].P, h->solver, EQLB_SCATTER_SLOTS, as, stream, h->mode);
+          const int st = eqlb::launch_se_patch(h->k, h->deg, h->bins[b].P, h->solver, EQLB_SCATTER_SLOTS, as, sp_stream, h->mode);
           if (st)
             return fail(st, "patch kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
         }
         if (evs && first_bin == 0)
-          HIP_TRY(hipEventRecord(evs[2 * b + 1], stream));
+          HIP_TRY(hipEventRecord(evs[2 * b + 1], sp_stream));
       }
     if (h->stress)
     {
@@ -1665,7 +1683,7 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
       // (se/reconstruction.hpp:237-270; the grouped boundary patches of :170-234 are flagged by the
       // patch builder: PFLAG_WS_SKIP / PFLAG_WS_GROUP)
       if (evs && first_bin == 0)
-        HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS + 2], stream));
+        HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS + 2], sp_stream));
       select_rhs(as, 0, true); // the kernel works on the slot rows of RHS 0 and 1
       // (overlapping groups of boundary patches: one pass per level, a pass skips the patches of other levels)
       for (int lv = 0; lv < h->ws_levels; ++lv)
@@ -1677,26 +1695,28 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
           as.slot_offset = bin_so(b);
           as.patch_offset = bin_po(b);
           as.ws_level = lv;
-          const int st = eqlb::launch_se_weaksym(h->k, h->bins[b].P, !h->stress_flux_bcs, as, stream);
+          const int st = eqlb::launch_se_weaksym(h->k, h->bins[b].P, !h->stress_flux_bcs, as, sp_stream);
           if (st)
             return fail(st, "weak-symmetry kernel launch failed (k=%d, P=%d)", h->k, h->bins[b].P);
         }
       if (evs && first_bin == 0)
-        HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS + 3], stream));
+        HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS + 3], sp_stream));
     }
     if (evs && first_bin == 0)
-      HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS], stream));
+      HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS], sp_stream));
     // blocks that lie behind one another (one array, the usual case) are reduced by one launch
     bool contiguous = true;
     for (int r = 1; r < h->nrhs; ++r)
       contiguous = contiguous && d_x[r] == d_x[0] + r * s_x;
     const int nlaunch = contiguous ? 1 : h->nrhs, per = contiguous ? h->nrhs : 1;
+    if (rest && sp_phase == 1)
+      return EQLB_OK;
     if (rest)
     {
       // only the cells that a patch of the generic kernels touches (the slot rows of their other vertices are zero)
       for (int r = 0; r < h->nrhs; ++r)
         if (eqlb::launch_reduce_slots_cells(h->nrt, m.ncells, h->nrest_cells, h->rest_cells,
-                                            h->slots + (size_t)r * s_slot * 3, d_x[r], stream))
+                                            h->slots + (size_t)r * s_slot * 3, d_x[r], sp_stream))
           return fail(EQLB_ERR_UNSUPPORTED, "compact slot reduction for %d DOFs per cell is not in this build", h->nrt);
       return EQLB_OK;
     }
@@ -1705,12 +1725,12 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
       const double* sl = h->slots + (size_t)l * s_slot * 3;
       if (ev_conf)
         eqlb::launch_ev_reduce(m, h->k, per, h->ev_cell_dofs, h->ev_ndofs, sl, d_x[l], accumulate, h->ev_basis,
-                               (h->ev_basis && h->ev_basis_has_R) ? h->ev_basis + h->nrt * h->nrt : nullptr, stream);
-      else if (eqlb::launch_reduce_slots(h->nrt, m.ncells, per, sl, d_x[l], accumulate, stream))
+                               (h->ev_basis && h->ev_basis_has_R) ? h->ev_basis + h->nrt * h->nrt : nullptr, sp_stream);
+      else if (eqlb::launch_reduce_slots(h->nrt, m.ncells, per, sl, d_x[l], accumulate, sp_stream))
         return fail(EQLB_ERR_UNSUPPORTED, "slot reduction for %d DOFs per cell is not in this build", h->nrt);
     }
     if (evs && first_bin == 0)
-      HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS + 1], stream));
+      HIP_TRY(hipEventRecord(evs[2 * eqlb::MAX_BINS + 1], sp_stream));
     return EQLB_OK;
   };
 
@@ -1737,6 +1757,33 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
     if (evs)
       HIP_TRY(hipEventRecord(evs[0], stream));
     int r0 = 0;
+    // the rest of a fused stress launch (boundary patches, interior patches that are not full, bins of more than 8
+    // lanes; with the last range of tiles of a two-phase sweep): its patch kernels - a handful of small launches,
+    // 50 us back to back at 1M triangles - run on a side stream NEXT TO the fused kernel, their sums are added
+    // behind it
+    const bool rest_now = stress_fused && h->t_rest > 0 && h->tile_first + tcount == h->ntiles;
+    if (rest_now)
+    {
+      if (!h->side_stream)
+      {
+        HIP_TRY(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+      }
+      HIP_TRY(hipEventRecord(h->ev_fork, stream));
+      HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+      hipEvent_t* keep = evs;
+      evs = nullptr;
+      sp_stream = h->side_stream;
+      sp_phase = 1;
+      const int st = run_slot_path(-1, 1);
+      sp_stream = stream;
+      sp_phase = 0;
+      evs = keep;
+      if (st)
+        return st;
+      HIP_TRY(hipEventRecord(h->ev_join, h->side_stream));
+    }
     if (stress_fused)
     {
       // rows 0, 1 of the stress and their weak symmetry in one launch
@@ -1776,13 +1823,14 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
       }
     if (evs)
       HIP_TRY(hipEventRecord(evs[1], stream));
-    // patches of more than 8 facets of a fused stress launch: generic kernels, sums added (with the last
-    // range of tiles of a two-phase sweep)
-    if (stress_fused && h->t_rest > 0 && h->tile_first + tcount == h->ntiles)
+    if (rest_now)
     {
+      HIP_TRY(hipStreamWaitEvent(stream, h->ev_join, 0));
       hipEvent_t* keep = evs;
       evs = nullptr;
+      sp_phase = 2;
       const int st = run_slot_path(-1, 1);
+      sp_phase = 0;
       evs = keep;
       if (st)
         return st;

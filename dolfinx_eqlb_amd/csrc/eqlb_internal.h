@@ -291,6 +291,8 @@ struct eqlb_se
   int32_t ntiles = 0, tile_tc = 0;
   bool t_stress = false;            // the tiles serve the fused stress launch (bins P <= 8 only)
   int64_t t_rest = 0;               // patches left to the generic kernels when t_stress (everything but full patches)
+  hipStream_t side_stream = nullptr; // the rest's patch kernels run here, next to the fused kernel
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int32_t* rest_cells = nullptr;    // cells with a vertex whose patch runs on the generic kernels (compact reduction)
   int64_t nrest_cells = 0;
   int64_t t_nslots = 0, t_npatch = 0;
