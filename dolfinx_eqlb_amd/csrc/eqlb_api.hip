@@ -631,6 +631,28 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
     }
   const double ext = std::max(bhi[0] - blo[0], bhi[1] - blo[1]);
   const double inv = (ext > 0.0) ? 1.0 / (3.0 * ext) : 0.0;
+  // the bisection on the device (one radix sort per level of the tree; eqlb_tiling_device.hip) unless the mesh
+  // has stretched cells, where the host bisection below picks the cuts of the last levels by their cost
+  bool on_device = false;
+  {
+    const char* env = getenv("EQLB_TILING");
+    if (!(env && !strcmp(env, "host")) && nc >= 4096)
+    {
+      std::vector<int32_t> dord;
+      const int r = eqlb::device_tile_order(m, TC, ntiles, blo, bhi, inv, dord);
+      if (r < 0)
+        return fail(EQLB_ERR_DEVICE, "tiling on the device failed");
+      if (r == 0)
+      {
+        for (int32_t p = 0; p < nc; ++p)
+          items[p] = {0.0f, 0.0f, dord[p]};
+        on_device = true;
+        tm.lap("tiles: bisection (device)");
+      }
+    }
+  }
+  if (!on_device)
+  {
   parallel_for(nc, 1 << 16, [&](int64_t c) {
     const int32_t* cn = &m.h_cell_nodes[3 * (size_t)c];
     double cx = 0.0, cy = 0.0;
@@ -657,6 +679,7 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
     std::sort(items.begin() + (size_t)t * TC, items.begin() + std::min<size_t>((size_t)(t + 1) * TC, nc),
               [](const TileItem& p, const TileItem& q) { return p.cell < q.cell; });
   });
+  }
   std::vector<int32_t> ord(nc);
   for (int32_t p = 0; p < nc; ++p)
     ord[p] = items[p].cell;

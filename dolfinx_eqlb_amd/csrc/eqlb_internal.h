@@ -231,6 +231,10 @@ void launch_halo_pack(int nrhs, int32_t nlist, int32_t nrt, int64_t ncells, cons
                       double* buf, int clear, hipStream_t stream);
 void launch_halo_unpack_add(int nrhs, int32_t nlist, int32_t nrt, int64_t ncells, const int64_t* cells,
                             double* x, const double* buf, hipStream_t stream);
+// tiles by recursive coordinate bisection on the device (eqlb_tiling_device.hip): 0 ok, 1 stretched mesh (host
+// bisection), < 0 device error
+int device_tile_order(const DeviceMesh& m, int tc, int32_t ntiles, const double blo[2], const double bhi[2], double inv,
+                      std::vector<int32_t>& order);
 size_t table_doubles(int k, int deg);
 int fill_tables_host(int k, int deg, std::vector<double>& out);
 

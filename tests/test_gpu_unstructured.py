@@ -74,3 +74,48 @@ def test_ev_and_stress_on_delaunay_mesh(oracle_mod):
     xs = eq.equilibrate_host(Gs, fs)
     refs = oracle_mod.se_reconstruct(mesh, k, ft2, Gs, fs, stress=True)
     assert np.abs(xs - refs).max() <= 1e-9 * np.abs(refs).max()
+
+
+@pytest.mark.parametrize("kind", ["square", "delaunay", "strip"])
+def test_device_bisection_of_the_tiles(oracle_mod, kind, monkeypatch):
+    """Tiles by recursive coordinate bisection on the device (one radix sort per level, eqlb_tiling_device.hip)
+    against the host bisection (EQLB_TILING=host): same number of tiles, a comparable number of patch instances
+    (both cut across the longer side of a segment's box), every cell in exactly one tile, and the same results
+    (to rounding: which wave-blocks run the specialised full-patch instance depends on the tiles)."""
+    from dolfinx_eqlb_amd import cpp
+    from dolfinx_eqlb_amd.mesh import create_mesh, create_rectangle, create_unit_square
+    from synthetic import facet_types, make_compatible_data
+    k = 2
+    if kind == "square":
+        mesh = create_unit_square(40, shuffle_seed=3, perturb=0.2)
+    elif kind == "strip":
+        mesh = create_rectangle(96, 12, 0.0, 8.0, 0.0, 1.0)
+    else:
+        from scipy.spatial import Delaunay
+        pts = np.random.default_rng(11).random((4000, 2))
+        cells = Delaunay(pts).simplices.astype(np.int32)
+        xx = pts[cells]
+        area = 0.5 * np.abs((xx[:, 1, 0] - xx[:, 0, 0]) * (xx[:, 2, 1] - xx[:, 0, 1])
+                            - (xx[:, 2, 0] - xx[:, 0, 0]) * (xx[:, 1, 1] - xx[:, 0, 1]))
+        cells = cells[area > 2e-5]
+        used = np.unique(cells)
+        remap = -np.ones(len(pts), dtype=np.int32)
+        remap[used] = np.arange(used.size, dtype=np.int32)
+        mesh = create_mesh(pts[used], remap[cells])
+    assert mesh.ncells >= 4096
+    ft = facet_types(mesh, None)
+    G, f = make_compatible_data(mesh, k, ft, seed=2)
+    out, info = {}, {}
+    for mode in ("host", "device"):
+        monkeypatch.setenv("EQLB_TILING", mode)
+        eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(mesh), k, 1)  # a new device mesh: the tile order is cached per mesh
+        eq.set_option("tile_cells", 64)
+        eq.set_boundary(ft)
+        out[mode] = eq.equilibrate_host(G[None], f[None])
+        info[mode] = eq.tiling_info()
+    ref = oracle_mod.se_reconstruct(mesh, k, ft, G[None], f[None])
+    for mode in out:
+        assert np.abs(out[mode] - ref).max() <= 1e-11 * np.abs(ref).max(), mode
+    assert np.abs(out["host"] - out["device"]).max() <= 1e-13 * np.abs(ref).max()
+    assert info["host"]["ntiles"] == info["device"]["ntiles"]
+    assert info["device"]["patch_instances"] <= 1.15 * info["host"]["patch_instances"]
