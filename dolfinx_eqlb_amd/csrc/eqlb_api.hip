@@ -738,17 +738,26 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
       wk.spawn([&work, ntiles, w, nt]() { work((int64_t)ntiles * w / nt, (int64_t)ntiles * (w + 1) / nt); });
     wk.join();
   };
+  // sort key of a node: 3 * bin + (full interior patch 0 | other interior patch 1 | boundary patch 2); -1: not listed
+  // (one byte per node, cache resident, instead of three scattered reads per visit of a node)
+  std::vector<int8_t> nkey(m.nnodes);
+  parallel_for(m.nnodes, 1 << 16, [&](int64_t nd) {
+    const int b_ = node_bin[nd];
+    if (b_ < 0)
+    {
+      nkey[nd] = -1;
+      return;
+    }
+    const bool interior = m.h_node_ncells[nd] == m.h_node_nfcts[nd]; // no boundary facet at the node
+    nkey[nd] = (int8_t)(3 * b_ + (interior ? ((m.h_node_ncells[nd] == eqlb::BIN_P[b_]) ? 0 : 1) : 2));
+  });
   tile_chunks([&](int64_t t0, int64_t t1) {
     std::vector<int32_t> stamp(m.nnodes, -1), seen(3 * (size_t)TC);
     for (int64_t t = t0; t < t1; ++t)
     {
       int nseen = 0;
       int32_t* cnt = &tcount[(size_t)t * 3 * NB];
-      auto key = [&](int32_t nd) {
-        const int b_ = node_bin[nd], Pb = eqlb::BIN_P[b_];
-        const bool interior = m.h_node_ncells[nd] == m.h_node_nfcts[nd]; // no boundary facet at the node
-        return 3 * b_ + (interior ? ((m.h_node_ncells[nd] == Pb) ? 0 : 1) : 2);
-      };
+      auto key = [&](int32_t nd) { return (int)nkey[nd]; };
       for (int q = 0; q < TC; ++q)
       {
         const int32_t c = tile_cells[(size_t)t * TC + q];
@@ -757,9 +766,9 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
         for (int j = 0; j < 3; ++j)
         {
           const int32_t nd = m.h_cell_nodes[3 * (size_t)c + j];
-          if (node_bin[nd] < 0)
+          if (nkey[nd] < 0)
             tiles[t].zero = 1; // masked-out vertex: the (cell, vertex) row of this tile stays unwritten
-          if (node_bin[nd] < 0 || stamp[nd] == (int32_t)t)
+          if (nkey[nd] < 0 || stamp[nd] == (int32_t)t)
             continue;
           stamp[nd] = (int32_t)t;
           seen[nseen++] = nd;
@@ -985,6 +994,7 @@ try
     return EQLB_ERR_DEVICE;
   }
   eqlb::launch_cell_geometry(ncells, d.x, d.cell_nodes, d.cellJ, nullptr);
+  eqlb::device_tiling_prepare(); // code object of the tile builder loaded here, not inside the first set_boundary
   if (hipDeviceSynchronize() != hipSuccess)
   {
     eqlb_mesh_destroy(m);

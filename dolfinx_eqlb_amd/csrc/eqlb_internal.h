@@ -233,6 +233,7 @@ void launch_halo_unpack_add(int nrhs, int32_t nlist, int32_t nrt, int64_t ncells
                             double* x, const double* buf, hipStream_t stream);
 // tiles by recursive coordinate bisection on the device (eqlb_tiling_device.hip): 0 ok, 1 stretched mesh (host
 // bisection), < 0 device error
+void device_tiling_prepare();
 int device_tile_order(const DeviceMesh& m, int tc, int32_t ntiles, const double blo[2], const double bhi[2], double inv,
                       std::vector<int32_t>& order);
 size_t table_doubles(int k, int deg);

@@ -21,6 +21,9 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace eqlb
@@ -200,6 +203,20 @@ struct DevBuf
 };
 } // namespace
 
+__global__ void k_tiling_touch(int* p)
+{
+  if (p && threadIdx.x == 1024)
+    *p = 0;
+}
+
+// HIP loads the code object of a translation unit at the first launch of one of its kernels (3 - 4 ms for this
+// one with its rocPRIM sort kernels): done when the mesh is created, not inside the first eqlb_se_set_boundary
+void device_tiling_prepare()
+{
+  hipLaunchKernelGGL(k_tiling_touch, dim3(1), dim3(1), 0, 0, (int*)nullptr);
+  (void)hipGetLastError();
+}
+
 // order [nc]: cells in tile order (tile t = positions [t TC, (t + 1) TC)), ascending ids inside a tile.
 // Returns 0 on success, 1 if the mesh has stretched cells (the caller takes the host bisection), < 0 on a device error.
 int device_tile_order(const DeviceMesh& m, int tc, int32_t ntiles, const double blo[2], const double bhi[2], double inv,
@@ -213,25 +230,63 @@ int device_tile_order(const DeviceMesh& m, int tc, int32_t ntiles, const double 
   for (int l = 0; l < nlevels; ++l)
     maxseg = std::max(maxseg, t.level_begin[l + 1] - t.level_begin[l]);
 
-  DevBuf d_cx, d_cy, d_ord[2], d_keys[2], d_off, d_n, d_nl, d_left, d_right, d_box[2], d_cnt, d_tmp;
-  if (!d_cx.alloc(sizeof(float) * nc) || !d_cy.alloc(sizeof(float) * nc) || !d_ord[0].alloc(sizeof(int32_t) * nc)
-      || !d_ord[1].alloc(sizeof(int32_t) * nc) || !d_keys[0].alloc(8 * (size_t)nc) || !d_keys[1].alloc(8 * (size_t)nc)
-      || !d_off.alloc(4 * (size_t)nseg_all) || !d_n.alloc(4 * (size_t)nseg_all) || !d_nl.alloc(4 * (size_t)nseg_all)
-      || !d_left.alloc(4 * (size_t)nseg_all) || !d_right.alloc(4 * (size_t)nseg_all)
-      || !d_box[0].alloc(16 * (size_t)maxseg) || !d_box[1].alloc(16 * (size_t)maxseg) || !d_cnt.alloc(8))
+  // EQLB_PROFILE_SETUP=1: wall time of the stages on stderr
+  const bool prof = getenv("EQLB_PROFILE_SETUP") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!prof)
+      return;
+    (void)hipDeviceSynchronize();
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[eqlb setup]   device tiling: %-20s %6.2f ms\n", what,
+            std::chrono::duration<double, std::milli>(t1 - t_last).count());
+    t_last = t1;
+  };
+  // one allocation for everything (a dozen hipMalloc / hipFree pairs cost more than the sorts)
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t b_f = up(sizeof(float) * (size_t)nc), b_i = up(sizeof(int32_t) * (size_t)nc), b_k = up(8 * (size_t)nc),
+               b_s = up(4 * (size_t)nseg_all), b_b = up(16 * (size_t)maxseg);
+  size_t tmp_bytes = 0;
+  if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                (int32_t*)nullptr, (int32_t*)nullptr, (size_t)nc, 0u, 64u, (hipStream_t)0)
+      != hipSuccess)
     return -1;
-  if (hipMemcpy(d_off.p, t.off.data(), 4 * (size_t)nseg_all, hipMemcpyHostToDevice) != hipSuccess
-      || hipMemcpy(d_n.p, t.n.data(), 4 * (size_t)nseg_all, hipMemcpyHostToDevice) != hipSuccess
-      || hipMemcpy(d_nl.p, t.nl.data(), 4 * (size_t)nseg_all, hipMemcpyHostToDevice) != hipSuccess
-      || hipMemcpy(d_left.p, t.left.data(), 4 * (size_t)nseg_all, hipMemcpyHostToDevice) != hipSuccess
-      || hipMemcpy(d_right.p, t.right.data(), 4 * (size_t)nseg_all, hipMemcpyHostToDevice) != hipSuccess
-      || hipMemset(d_cnt.p, 0, 8) != hipSuccess)
+  const size_t total = 2 * b_f + 2 * b_i + 2 * b_k + 5 * b_s + 2 * b_b + 256 + up(tmp_bytes);
+  DevBuf pool;
+  if (!pool.alloc(total))
     return -1;
+  char* base = pool.as<char>();
+  auto take = [&](size_t b) {
+    char* q = base;
+    base += b;
+    return q;
+  };
+  float* cx = reinterpret_cast<float*>(take(b_f));
+  float* cy = reinterpret_cast<float*>(take(b_f));
+  int32_t* ord2[2] = {reinterpret_cast<int32_t*>(take(b_i)), reinterpret_cast<int32_t*>(take(b_i))};
+  unsigned long long* keys2[2] = {reinterpret_cast<unsigned long long*>(take(b_k)),
+                                  reinterpret_cast<unsigned long long*>(take(b_k))};
+  int32_t* s_off = reinterpret_cast<int32_t*>(take(b_s));
+  int32_t* s_n = reinterpret_cast<int32_t*>(take(b_s));
+  int32_t* s_nl = reinterpret_cast<int32_t*>(take(b_s));
+  int32_t* s_left = reinterpret_cast<int32_t*>(take(b_s));
+  int32_t* s_right = reinterpret_cast<int32_t*>(take(b_s));
+  float* box2[2] = {reinterpret_cast<float*>(take(b_b)), reinterpret_cast<float*>(take(b_b))};
+  unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(take(256));
+  void* d_tmp = take(up(tmp_bytes));
+  if (hipMemcpyAsync(s_off, t.off.data(), 4 * (size_t)nseg_all, hipMemcpyHostToDevice, 0) != hipSuccess
+      || hipMemcpyAsync(s_n, t.n.data(), 4 * (size_t)nseg_all, hipMemcpyHostToDevice, 0) != hipSuccess
+      || hipMemcpyAsync(s_nl, t.nl.data(), 4 * (size_t)nseg_all, hipMemcpyHostToDevice, 0) != hipSuccess
+      || hipMemcpyAsync(s_left, t.left.data(), 4 * (size_t)nseg_all, hipMemcpyHostToDevice, 0) != hipSuccess
+      || hipMemcpyAsync(s_right, t.right.data(), 4 * (size_t)nseg_all, hipMemcpyHostToDevice, 0) != hipSuccess
+      || hipMemsetAsync(d_cnt, 0, 8, 0) != hipSuccess)
+    return -1;
+  lap("alloc + tree");
   const unsigned grid = (unsigned)((nc + 255) / 256);
-  hipLaunchKernelGGL(k_centroids, dim3(grid), dim3(256), 0, 0, nc, m.x, m.cell_nodes, blo[0], blo[1], inv,
-                     d_cx.as<float>(), d_cy.as<float>(), d_ord[0].as<int32_t>(), d_cnt.as<unsigned long long>());
+  hipLaunchKernelGGL(k_centroids, dim3(grid), dim3(256), 0, 0, nc, m.x, m.cell_nodes, blo[0], blo[1], inv, cx, cy,
+                     ord2[0], d_cnt);
   unsigned long long nstretched = 0;
-  if (hipMemcpy(&nstretched, d_cnt.p, 8, hipMemcpyDeviceToHost) != hipSuccess)
+  if (hipMemcpy(&nstretched, d_cnt, 8, hipMemcpyDeviceToHost) != hipSuccess)
     return -1;
   if (nstretched * 1000ull > (unsigned long long)nc)
     return 1;
@@ -239,19 +294,13 @@ int device_tile_order(const DeviceMesh& m, int tc, int32_t ntiles, const double 
     // root box: the box of the NODES in the scale of the centroids (the centroids lie inside it; only the ratio
     // of its sides matters for the choice of the first cut)
     float b[4] = {0.0f, (float)((bhi[0] - blo[0]) * 3.0 * inv), 0.0f, (float)((bhi[1] - blo[1]) * 3.0 * inv)};
-    if (hipMemcpy(d_box[0].p, b, sizeof(b), hipMemcpyHostToDevice) != hipSuccess)
+    if (hipMemcpy(box2[0], b, sizeof(b), hipMemcpyHostToDevice) != hipSuccess)
       return -1;
   }
-  size_t tmp_bytes = 0;
+  lap("centroids");
   unsigned end_bit = 32;
   for (int32_t v = maxseg; v > 0; v >>= 1)
     ++end_bit;
-  if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys[0].as<unsigned long long>(), d_keys[1].as<unsigned long long>(),
-                                d_ord[0].as<int32_t>(), d_ord[1].as<int32_t>(), (size_t)nc, 0u, 64u, (hipStream_t)0)
-      != hipSuccess)
-    return -1;
-  if (!d_tmp.alloc(tmp_bytes))
-    return -1;
   int cur = 0, bx = 0;
   for (int l = 0; l < nlevels; ++l)
   {
@@ -261,12 +310,10 @@ int device_tile_order(const DeviceMesh& m, int tc, int32_t ntiles, const double 
       any = t.nl[first + s] > 0;
     if (!any)
       break;
-    hipLaunchKernelGGL(k_level_keys, dim3(grid), dim3(256), 0, 0, nc, nseg, d_off.as<int32_t>() + first,
-                       d_nl.as<int32_t>() + first, d_box[bx].as<float>(), d_cx.as<float>(), d_cy.as<float>(),
-                       d_ord[cur].as<int32_t>(), d_keys[0].as<unsigned long long>());
+    hipLaunchKernelGGL(k_level_keys, dim3(grid), dim3(256), 0, 0, nc, nseg, s_off + first, s_nl + first, box2[bx], cx,
+                       cy, ord2[cur], keys2[0]);
     size_t tb = tmp_bytes;
-    if (rocprim::radix_sort_pairs(d_tmp.p, tb, d_keys[0].as<unsigned long long>(), d_keys[1].as<unsigned long long>(),
-                                  d_ord[cur].as<int32_t>(), d_ord[1 - cur].as<int32_t>(), (size_t)nc, 0u, end_bit,
+    if (rocprim::radix_sort_pairs(d_tmp, tb, keys2[0], keys2[1], ord2[cur], ord2[1 - cur], (size_t)nc, 0u, end_bit,
                                   (hipStream_t)0)
         != hipSuccess)
       return -1;
@@ -274,28 +321,30 @@ int device_tile_order(const DeviceMesh& m, int tc, int32_t ntiles, const double 
     if (l + 1 < nlevels)
     {
       const int32_t nfirst = t.level_begin[l + 1];
-      hipLaunchKernelGGL(k_level_children, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, 0, nseg,
-                         d_off.as<int32_t>() + first, d_n.as<int32_t>() + first, d_nl.as<int32_t>() + first,
-                         d_left.as<int32_t>() + first, d_right.as<int32_t>() + first, first, nfirst,
-                         d_box[bx].as<float>(), d_box[1 - bx].as<float>(), d_keys[1].as<unsigned long long>());
+      hipLaunchKernelGGL(k_level_children, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, 0, nseg, s_off + first,
+                         s_n + first, s_nl + first, s_left + first, s_right + first, first, nfirst, box2[bx],
+                         box2[1 - bx], keys2[1]);
       bx = 1 - bx;
     }
   }
+  lap("levels");
   // ascending cell ids inside a tile
-  hipLaunchKernelGGL(k_tile_keys, dim3(grid), dim3(256), 0, 0, nc, tc, d_ord[cur].as<int32_t>(),
-                     d_keys[0].as<unsigned long long>());
+  hipLaunchKernelGGL(k_tile_keys, dim3(grid), dim3(256), 0, 0, nc, tc, ord2[cur], keys2[0]);
   {
     size_t tb = tmp_bytes;
-    if (rocprim::radix_sort_pairs(d_tmp.p, tb, d_keys[0].as<unsigned long long>(), d_keys[1].as<unsigned long long>(),
-                                  d_ord[cur].as<int32_t>(), d_ord[1 - cur].as<int32_t>(), (size_t)nc, 0u, 64u,
-                                  (hipStream_t)0)
+    unsigned tile_bits = 0;
+    for (int32_t v = ntiles; v > 0; v >>= 1)
+      ++tile_bits;
+    if (rocprim::radix_sort_pairs(d_tmp, tb, keys2[0], keys2[1], ord2[cur], ord2[1 - cur], (size_t)nc, 0u,
+                                  32u + tile_bits, (hipStream_t)0)
         != hipSuccess)
       return -1;
     cur = 1 - cur;
   }
   order.resize((size_t)nc);
-  if (hipMemcpy(order.data(), d_ord[cur].p, sizeof(int32_t) * (size_t)nc, hipMemcpyDeviceToHost) != hipSuccess)
+  if (hipMemcpy(order.data(), ord2[cur], sizeof(int32_t) * (size_t)nc, hipMemcpyDeviceToHost) != hipSuccess)
     return -1;
+  lap("tile sort + download");
   return (hipGetLastError() == hipSuccess) ? 0 : -1;
 }
 

@@ -83,7 +83,7 @@ def test_device_bisection_of_the_tiles(oracle_mod, kind, monkeypatch):
     (both cut across the longer side of a segment's box), every cell in exactly one tile, and the same results
     (to rounding: which wave-blocks run the specialised full-patch instance depends on the tiles)."""
     from dolfinx_eqlb_amd import cpp
-    from dolfinx_eqlb_amd.mesh import create_mesh, create_rectangle, create_unit_square
+    from dolfinx_eqlb_amd.mesh import create_rectangle, create_unit_square
     from synthetic import facet_types, make_compatible_data
     k = 2
     if kind == "square":
@@ -91,17 +91,7 @@ def test_device_bisection_of_the_tiles(oracle_mod, kind, monkeypatch):
     elif kind == "strip":
         mesh = create_rectangle(96, 12, 0.0, 8.0, 0.0, 1.0)
     else:
-        from scipy.spatial import Delaunay
-        pts = np.random.default_rng(11).random((4000, 2))
-        cells = Delaunay(pts).simplices.astype(np.int32)
-        xx = pts[cells]
-        area = 0.5 * np.abs((xx[:, 1, 0] - xx[:, 0, 0]) * (xx[:, 2, 1] - xx[:, 0, 1])
-                            - (xx[:, 2, 0] - xx[:, 0, 0]) * (xx[:, 1, 1] - xx[:, 0, 1]))
-        cells = cells[area > 2e-5]
-        used = np.unique(cells)
-        remap = -np.ones(len(pts), dtype=np.int32)
-        remap[used] = np.arange(used.size, dtype=np.int32)
-        mesh = create_mesh(pts[used], remap[cells])
+        mesh = delaunay_mesh(2600, seed=5)
     assert mesh.ncells >= 4096
     ft = facet_types(mesh, None)
     G, f = make_compatible_data(mesh, k, ft, seed=2)
