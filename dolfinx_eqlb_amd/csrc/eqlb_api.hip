@@ -248,6 +248,28 @@ static inline bool rcb_less(const TileItem& p, const TileItem& q, int axis)
   return u < v || (u == v && p.cell < q.cell);
 }
 
+// std::vector without value initialisation: the big scratch arrays of the tile builder are written completely by the
+// worker threads - a zero fill by the calling thread would touch (page-fault) tens of MB serially first
+template <typename T>
+struct default_init_alloc : std::allocator<T>
+{
+  template <typename U>
+  struct rebind
+  {
+    using other = default_init_alloc<U>;
+  };
+  template <typename U, typename... A>
+  void construct(U* p, A&&... a)
+  {
+    if constexpr (sizeof...(A) == 0)
+      ::new (static_cast<void*>(p)) U;
+    else
+      ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
+  }
+};
+template <typename T>
+using uvec = std::vector<T, default_init_alloc<T>>;
+
 // Host worker threads of the set-up: capped (the tile builder keeps an O(nnodes) stamp per worker: 16 MB each at
 // 4M nodes, on every rank of a node) and exception safe - an exception inside a std::thread would call
 // std::terminate; the first one is kept and re-thrown by join() in the calling thread, where the C entry points
@@ -605,7 +627,7 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
       TC = (int)std::min<int64_t>(h->tile_cells_user, tcmax);
   }
   SetupTimer tm;
-  std::vector<TileItem> items(nc);
+  uvec<TileItem> items(nc);
   const int32_t ntiles = (nc + TC - 1) / TC;
   bool cached = false;
   {
@@ -690,13 +712,17 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
   // first launch over them, the halo exchange, and the launch over the rest then overlap
   std::vector<int32_t> order(ntiles);
   {
-    std::vector<uint8_t> is_prio(nc, 0), tile_prio(ntiles, 0);
-    for (int32_t c : h->prio_cells)
-      if (c >= 0 && c < nc)
-        is_prio[c] = 1;
-    for (int32_t p = 0; p < nc; ++p)
-      if (is_prio[items[p].cell])
-        tile_prio[p / TC] = 1;
+    std::vector<uint8_t> tile_prio(ntiles, 0);
+    if (!h->prio_cells.empty())
+    {
+      std::vector<uint8_t> is_prio(nc, 0);
+      for (int32_t c : h->prio_cells)
+        if (c >= 0 && c < nc)
+          is_prio[c] = 1;
+      for (int32_t p = 0; p < nc; ++p)
+        if (is_prio[items[p].cell])
+          tile_prio[p / TC] = 1;
+    }
     int32_t np = 0;
     for (int32_t t = 0; t < ntiles; ++t)
       if (tile_prio[t])
@@ -707,24 +733,25 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
         order[np++] = t;
   }
   tm.lap("tiles: sort + priority");
-  std::vector<int32_t> tile_cells((size_t)ntiles * TC, -1), cell_tile(nc), cell_pos(nc);
-  for (int32_t t = 0; t < ntiles; ++t)
-  {
+  uvec<int32_t> tile_cells((size_t)ntiles * TC), cell_tile(nc), cell_pos(nc);
+  parallel_for(ntiles, 16, [&](int64_t t) {
     const int64_t src = (int64_t)order[t] * TC, len = std::min<int64_t>(TC, nc - src);
     for (int64_t q = 0; q < len; ++q)
     {
       const int32_t c = items[src + q].cell;
       tile_cells[(size_t)t * TC + q] = c;
-      cell_tile[c] = t;
+      cell_tile[c] = (int32_t)t;
       cell_pos[c] = (int32_t)((int64_t)t * TC + q);
     }
-  }
+    for (int64_t q = len; q < TC; ++q)
+      tile_cells[(size_t)t * TC + q] = -1;
+  });
   std::vector<eqlb::TileDesc> tiles(ntiles);
   // pass 1 (host threads, a chunk of tiles each): the nodes of every tile by bin - full interior patches
   // (as many cells as lanes, no boundary facet: their wave-blocks run the specialised body of the kernel)
   // first -, in order of first appearance; flat storage, 3 TC entries per tile
   constexpr int NB = eqlb::MAX_BINS;
-  std::vector<int32_t> tnodes((size_t)ntiles * 3 * TC);
+  uvec<int32_t> tnodes((size_t)ntiles * 3 * TC);
   std::vector<int32_t> tcount((size_t)ntiles * 3 * NB, 0); // [tile][bin][full, interior, other]
   auto tile_chunks = [&](auto work) {
     const int64_t nt = host_workers(ntiles / 32);
@@ -813,7 +840,7 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
       if (slotctr > 0x7fffff00)
         return fail(EQLB_ERR_UNSUPPORTED, "tiled patch SoA exceeds 2^31 lane slots");
     }
-  std::vector<int32_t> inst_node((size_t)ninst), inst_slot((size_t)ninst), inst_tile((size_t)ninst);
+  uvec<int32_t> inst_node((size_t)ninst), inst_slot((size_t)ninst), inst_tile((size_t)ninst);
   tile_chunks([&](int64_t t0, int64_t t1) {
     for (int64_t t = t0; t < t1; ++t)
     {
