@@ -682,7 +682,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 #pragma unroll
       for (int q = 0; q < NDIV; ++q)
         full[2 * K + q] = sgn * Rq[1 + q];
-      const double* wq = row16<AL>(sWQ + (HALFWQ ? (ci >> 1) : ci) * 3 * NH * NCOLS);
+      const double* wq = row16<AL>(sWQ + (HALFWQ ? (ci >> 1) * Z::NCMBH : ci * 3 * NH * NCOLS));
 #pragma unroll
       for (int h = 0; h < NH; ++h)
       {
@@ -1832,12 +1832,12 @@ constexpr int tile_threads_c(int k) { return (k >= 3) ? EQLB_TILE_THREADS_K3 : E
 #define EQLB_TILE_CELLS 480 // 480 cells x 18 packed values + tables: two workgroups per CU (SE and EV)
 #endif
 #ifndef EQLB_TILE_CELLS_K3
-#define EQLB_TILE_CELLS_K3 492 // LARGEST tile: 492 cells x 36 packed values (141.7 KB) + 21.2 KB of tables (half of WQ) of the 160 KB: one workgroup per CU; the tile builder picks the size that fills whole rounds of the 256 slots
+#define EQLB_TILE_CELLS_K3 491 // LARGEST tile: 492 cells x 36 packed values (141.7 KB) + 21.2 KB of tables (half of WQ) of the 160 KB: one workgroup per CU; the tile builder picks the size that fills whole rounds of the 256 slots
                                // (measured at 1M triangles: 256 threads / 160 cells 0.384 ms, 512 / 320 0.366, 512 / 440 0.339)
 #endif
 constexpr int tile_cells_c(int k) { return (k >= 3) ? EQLB_TILE_CELLS_K3 : EQLB_TILE_CELLS; }
 #ifndef EQLB_TILE_CELLS_K3_EV
-#define EQLB_TILE_CELLS_K3_EV 468 // EV mode stages 7.2 KB more tensors (HG, WG)
+#define EQLB_TILE_CELLS_K3_EV 467 // EV mode stages 7.2 KB more tensors (HG, WG)
 #endif
 // largest tile the LDS budget of two workgroups per CU allows (k <= 2: 490 x 144 B + tensors <= 80 KB)
 constexpr int tile_cells_max_c(int k) { return (k >= 3) ? EQLB_TILE_CELLS_K3 : (EQLB_TILE_CELLS > 490 ? EQLB_TILE_CELLS : 490); }
@@ -1923,11 +1923,11 @@ __device__ __forceinline__ void tile_stage(const SeArgs& a0, const TileArgs& ta,
   if constexpr (HALFWQ)
   {
     constexpr int NHEAD = Z::NF + Z::NHT + Z::NDT + Z::NTET; // F | H | D | TE
-    constexpr int NCMB = 3 * Z::NH * Z::NCOLS;               // one combination of WQ
+    constexpr int NCMB = Z::NCMB;                            // one combination of WQ (NCMBH: its padded stride in LDS)
     for (int i = threadIdx.x; i < NHEAD; i += TILE_THREADS)
       lds[i] = a0.tables[Z::NS + i];
-    for (int i = threadIdx.x; i < Z::NWQH; i += TILE_THREADS) // combinations 0, 2, 4, ...: no reversal
-      lds[NHEAD + i] = a0.tables[Z::NS + NHEAD + (i / NCMB) * 2 * NCMB + (i % NCMB)];
+    for (int i = threadIdx.x; i < (NCOMBO / 2) * NCMB; i += TILE_THREADS) // combinations 0, 2, 4, ...: no reversal
+      lds[NHEAD + (i / NCMB) * Z::NCMBH + (i % NCMB)] = a0.tables[Z::NS + NHEAD + (i / NCMB) * 2 * NCMB + (i % NCMB)];
     for (int i = threadIdx.x; i < Z::NHB; i += TILE_THREADS)
       lds[NHEAD + Z::NWQH + i] = a0.tables[Z::NS + NHEAD + Z::NWQT + i];
   }
