@@ -23,6 +23,9 @@ trace ev3 --steps 100 --ev --k 3
 trace k2_r4 --steps 100 --nrhs 4
 trace k4 --steps 50 --k 4 --n 250
 fi
+if [ "$WHAT" = stress ]; then
+trace stress --steps 100 --stress
+fi
 if [ "$WHAT" = pmc ]; then
 bash tools/pmc_kernel.sh k_se_patch_tiled r3p/pmc_headline > $O/pmc_headline.log 2>&1; cp $O/pmc_headline/summary.csv $O/headline_pmc.csv
 bash tools/pmc_kernel.sh k_se_stress_tiled r3p/pmc_stress --stress > $O/pmc_stress.log 2>&1; cp $O/pmc_stress/summary.csv $O/stress_pmc.csv
