@@ -1680,7 +1680,9 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
       if (upload<double>(&h->slots, nullptr, n_slot * 3))
         return EQLB_ERR_DEVICE;
       // slots of (cell, vertex) pairs whose node is not equilibrated here (node_mask, other path) stay zero
-      HIP_TRY(hipMemset(h->slots, 0, n_slot * 3 * sizeof(double)));
+      // (on the stream of the patch kernels: a fill on the null stream is not ordered against the non-blocking side
+      // stream of a fused stress launch and could wipe rows its kernels have already written)
+      HIP_TRY(hipMemsetAsync(h->slots, 0, n_slot * 3 * sizeof(double), sp_stream));
       h->slots_first_bin = eqlb::MAX_BINS;
     }
     // The reduction adds ALL slot rows of a cell.  A run over the bins >= first_bin rewrites only their rows: rows

@@ -138,7 +138,7 @@ __host__ __device__ constexpr int combo_index(int fm, int fp, bool rev)
 
 // ---- compile-time sizes of a (K, DEG, P) patch kernel ------------------------------------------
 #ifndef EQLB_WQ_PAD
-#define EQLB_WQ_PAD 13
+#define EQLB_WQ_PAD 0 // 13 was measured: RT_3 0.300 -> 0.325 ms at 1M triangles, 2.30 -> 2.47 at 8M (see Sizes::NCMBH)
 #endif
 template <int K, int DEG, int P>
 struct Sizes
@@ -172,10 +172,11 @@ struct Sizes
   // RT_3 tiles stage only the combinations WITHOUT the reversal flag of the load tensor (half of WQ: the LDS
   // decides their tile size); for a reversed minus facet the load follows from Q_rev = Q blockdiag(B, I):
   // load_h = sum_j B[j][h] load_j for the K unknowns [d | um] (se_patch_body, HALFWQ)
-  // The combinations of the staged half are PADDED: a wave reads the same (row, column) of different combinations
-  // at once, and their natural stride of 3 NH NCOLS doubles (k = 3: 216 doubles = 432 dwords = 16 mod 32 banks) puts
-  // three of the six combinations on the same banks of a ds_read2_b64; 13 doubles more (458 dwords = 10 mod 32, mod
-  // 64) give every combination banks of its own
+  // EQLB_WQ_PAD > 0 pads the combinations of the staged half: a wave reads the same (row, column) of different
+  // combinations at once, and their natural stride of 3 NH NCOLS doubles (k = 3: 216 doubles = 432 dwords = 16 mod 32
+  // banks) puts three of the six combinations on the same banks of a ds_read2_b64.  Built with 13 doubles more (458
+  // dwords, banks of its own for every combination) and measured SLOWER (0.325 against 0.300 ms: the rows lose their
+  // 16-byte alignment, the reads are no longer paired) - kept at 0
   static constexpr int NCMB = 3 * NH * NCOLS, NCMBH = NCMB + ((K == 3) ? EQLB_WQ_PAD : 0);
   static constexpr int NWQH = (NCOMBO / 2) * NCMBH, NTAB_HALF = NTAB - NWQT + NWQH;
   // workgroup size: as many waves as fit a 64 KiB LDS budget for the dense tiles (at least one)

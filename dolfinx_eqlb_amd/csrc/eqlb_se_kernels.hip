@@ -1832,12 +1832,12 @@ constexpr int tile_threads_c(int k) { return (k >= 3) ? EQLB_TILE_THREADS_K3 : E
 #define EQLB_TILE_CELLS 480 // 480 cells x 18 packed values + tables: two workgroups per CU (SE and EV)
 #endif
 #ifndef EQLB_TILE_CELLS_K3
-#define EQLB_TILE_CELLS_K3 491 // LARGEST tile: 492 cells x 36 packed values (141.7 KB) + 21.2 KB of tables (half of WQ) of the 160 KB: one workgroup per CU; the tile builder picks the size that fills whole rounds of the 256 slots
+#define EQLB_TILE_CELLS_K3 492 // LARGEST tile: 492 cells x 36 packed values (141.7 KB) + 21.2 KB of tables (half of WQ) of the 160 KB: one workgroup per CU; the tile builder picks the size that fills whole rounds of the 256 slots
                                // (measured at 1M triangles: 256 threads / 160 cells 0.384 ms, 512 / 320 0.366, 512 / 440 0.339)
 #endif
 constexpr int tile_cells_c(int k) { return (k >= 3) ? EQLB_TILE_CELLS_K3 : EQLB_TILE_CELLS; }
 #ifndef EQLB_TILE_CELLS_K3_EV
-#define EQLB_TILE_CELLS_K3_EV 467 // EV mode stages 7.2 KB more tensors (HG, WG)
+#define EQLB_TILE_CELLS_K3_EV 468 // EV mode stages 7.2 KB more tensors (HG, WG)
 #endif
 // largest tile the LDS budget of two workgroups per CU allows (k <= 2: 490 x 144 B + tensors <= 80 KB)
 constexpr int tile_cells_max_c(int k) { return (k >= 3) ? EQLB_TILE_CELLS_K3 : (EQLB_TILE_CELLS > 490 ? EQLB_TILE_CELLS : 490); }

@@ -158,9 +158,10 @@ def _boundary_cells(mesh, facets):
     return cells, lf
 
 
-def solve_elasticity(mesh, k, ft, seed=0):
+def solve_elasticity(mesh, k, ft, seed=0, traction=None, body_force=True):
     """u_h in P_k^2 with u_r = 0 on the facets ft[r] == 1 and traction component t_r (trace of a random
-    DG_{k-1} function) on ft[r] == 2; body force random DG_{k-1}^2.
+    DG_{k-1} function; `traction(r, x, y)` if given: prescribed values, polynomial of degree < k per facet)
+    on ft[r] == 2; body force random DG_{k-1}^2 (zero with body_force=False).
     Returns (G [2, ncells*nd*2] rows of -sigma(u_h) as DG_{k-1}^2 nodal values, f [2, ncells*nd],
     boundary_values [2, ncells*k(k+2)] = global boundary DOFs of the prescribed normal flux -t_r)."""
     from dolfinx_eqlb_amd.elmtlib import e_raviart_thomas as ert
@@ -189,6 +190,8 @@ def solve_elasticity(mesh, k, ft, seed=0):
     A = sp.csr_matrix((Ke.ravel(), (np.repeat(vd, 2 * nl, axis=1).ravel(), np.tile(vd, (1, 2 * nl)).ravel())),
                       shape=(2 * ns, 2 * ns))
     f = 2.0 * (rng.random((2, mesh.ncells, nd)) + 0.1)
+    if not body_force:
+        f[:] = 0.0
     psi = dg.tabulate(qp)[0]                                 # [q, nd]
     b = np.zeros(2 * ns)
     for r in range(2):
@@ -213,6 +216,10 @@ def solve_elasticity(mesh, k, ft, seed=0):
             va, vb = [(1, 2), (0, 2), (0, 1)][fl]
             length = np.linalg.norm(xc[cells[sel], vb] - xc[cells[sel], va], axis=1)
             tq = tdg[r][cells[sel]] @ dg.tabulate(pts)[0].T  # [c, q]
+            if traction is not None:
+                xq = xc[cells[sel], 0][:, None, :] + np.einsum(
+                    "qX,cXd->cqd", pts, xc[cells[sel]][:, 1:] - xc[cells[sel]][:, :1])
+                tq = np.broadcast_to(np.asarray(traction(r, xq[..., 0], xq[..., 1]), dtype=float), tq.shape)
             fe = np.einsum("c,q,cq,qi->ci", length, wq, tq, el.tabulate(pts)[0])
             np.add.at(b, (2 * cd[cells[sel]] + r).ravel(), fe.ravel())
             # D_{f,j} = int_0^1 (detJ K w) . N_f s^j ds with w . n_out = -t_r
