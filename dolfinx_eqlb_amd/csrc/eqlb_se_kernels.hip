@@ -24,6 +24,16 @@
 #include "eqlb_device_common.h"
 #include "eqlb_tables_gen.h"
 
+// Parallel cyclic reduction, couplings across the ends of a chain: the coupling a_i of row i to row i - s is an exact
+// zero for i < s at every level s (lane 0 is the border row, a_1 couples to it and is dropped; a level maps
+// a_i -> -a_i / b_{i-s} * a_{i-s}, which keeps the zeros of i < 2 s), in EVERY patch group of a wave (idle groups:
+// identity rows).  So what a row shift drags in from the first rows of the NEXT group as "coupling to row i + s" is
+// already zero, and so is the product that forms the new a_i for i < 2 s: the selects that forced these zeros
+// (1: as in rounds 1 - 2) cost 4 v_cndmask per level.
+#ifndef EQLB_PCR_SELECTS
+#define EQLB_PCR_SELECTS 0
+#endif
+
 namespace eqlb
 {
 
@@ -1186,13 +1196,13 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
     const double r0_lo = dpp_d<0x110 + S>(r0), r1_lo = dpp_d<0x110 + S>(r1), r2_lo = dpp_d<0x110 + S>(r2); \
     const double ib_hi = dpp_d<0x100 + S>(ib), a_hi = dpp_d<0x100 + S>(am);                        \
     const double r0_hi = dpp_d<0x100 + S>(r0), r1_hi = dpp_d<0x100 + S>(r1), r2_hi = dpp_d<0x100 + S>(r2); \
-    const double cp = (sub + S < P) ? a_hi : 0.0; /* coupling to row i + S */                      \
+    const double cp = EQLB_PCR_SELECTS ? ((sub + S < P) ? a_hi : 0.0) : a_hi; /* coupling to row i + S */ \
     const double al = am * ib_lo, ga = cp * ib_hi;                                                 \
     b = __builtin_fma(-ga, cp, __builtin_fma(-al, am, b));                                         \
     r0 = __builtin_fma(-ga, r0_hi, __builtin_fma(-al, r0_lo, r0));                                 \
     r1 = __builtin_fma(-ga, r1_hi, __builtin_fma(-al, r1_lo, r1));                                 \
     r2 = __builtin_fma(-ga, r2_hi, __builtin_fma(-al, r2_lo, r2));                                 \
-    am = (sub >= 2 * S) ? -al * a_lo : 0.0;                                                        \
+    am = EQLB_PCR_SELECTS ? ((sub >= 2 * S) ? -al * a_lo : 0.0) : -al * a_lo;                      \
   }
         EQLB_PCR_LEVEL(1)
         EQLB_PCR_LEVEL(2)
@@ -1333,7 +1343,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         {                                                                                             \
           Al[aa][e] = dpp_d<0x110 + S>(A[aa][e]);                                                     \
           const double t = dpp_d<0x100 + S>(A[aa][e]);                                                \
-          Ah[aa][e] = (P < 16 && !(sub + S < P)) ? 0.0 : t; /* row i + S of ANOTHER group */          \
+          Ah[aa][e] = (EQLB_PCR_SELECTS && P < 16 && !(sub + S < P)) ? 0.0 : t; /* row i + S of ANOTHER group */ \
         }                                                                                             \
         _Pragma("unroll") for (int c = 0; c < 1 + W; ++c)                                             \
         {                                                                                             \

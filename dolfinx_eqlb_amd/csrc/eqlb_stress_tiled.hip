@@ -101,6 +101,9 @@ __device__ __forceinline__ void ldrow_pair(const double* p, double (&r)[2])
 // b: diagonal, am: coupling to row i - 1 (0 in lane 0), rows outside the chain are identity rows with
 // zero couplings; what a shift drags in from a neighbouring patch group is multiplied by an exact zero.
 // The multipliers of the levels are returned for later columns (pcr_apply).
+#ifndef EQLB_PCR_SELECTS
+#define EQLB_PCR_SELECTS 0 // see eqlb_se_kernels.hip
+#endif
 template <int P>
 struct PcrMult
 {
@@ -118,7 +121,7 @@ __device__ __forceinline__ void pcr_level(double& b, double& am, double (&r)[NC]
     const double ib = rcp_d(b);
     const double ib_lo = dpp_d<0x110 + S>(ib), a_lo = dpp_d<0x110 + S>(am);
     const double ib_hi = dpp_d<0x100 + S>(ib), a_hi = dpp_d<0x100 + S>(am);
-    const double cp = (sub + S < P) ? a_hi : 0.0; // coupling to row i + S
+    const double cp = EQLB_PCR_SELECTS ? ((sub + S < P) ? a_hi : 0.0) : a_hi; // coupling to row i + S (eqlb_se_kernels.hip)
     const double al = am * ib_lo, ga = cp * ib_hi;
     b = __builtin_fma(-ga, cp, __builtin_fma(-al, am, b));
 #pragma unroll
@@ -127,7 +130,7 @@ __device__ __forceinline__ void pcr_level(double& b, double& am, double (&r)[NC]
       const double lo = dpp_d<0x110 + S>(r[c]), hi = dpp_d<0x100 + S>(r[c]);
       r[c] = __builtin_fma(-ga, hi, __builtin_fma(-al, lo, r[c]));
     }
-    am = (sub >= 2 * S) ? -al * a_lo : 0.0;
+    am = EQLB_PCR_SELECTS ? ((sub >= 2 * S) ? -al * a_lo : 0.0) : -al * a_lo;
     m.al[L] = al;
     m.ga[L] = ga;
   }
