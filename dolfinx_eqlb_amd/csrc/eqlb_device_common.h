@@ -76,10 +76,35 @@ __device__ __forceinline__ double lane_up1_d(double v, int gbase, int sub)
     return __shfl(v, gbase + ((sub + 1 < P) ? sub + 1 : sub), 64);
 }
 // sum over the P lanes of a group, result in every lane
+// EQLB_GSUM_SWIZZLE: the butterfly of group_sum_d through ds_swizzle_b32 (LDS crossbar, no LDS memory, no address
+// register) instead of DPP moves: the same pairs in the same order, bit-identical sums; 2 VALU issue slots less per
+// step at the price of the LDS pipe's latency
+#ifndef EQLB_GSUM_SWIZZLE
+#define EQLB_GSUM_SWIZZLE 0
+#endif
+template <int XOR>
+__device__ __forceinline__ double swizzle_xor_d(double v)
+{
+  constexpr int PAT = (XOR << 10) | 0x1f; // bit-mask mode: lane' = ((lane & 0x1f) | 0) ^ XOR within 32 lanes
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_ds_swizzle(lo, PAT);
+  hi = __builtin_amdgcn_ds_swizzle(hi, PAT);
+  return __hiloint2double(hi, lo);
+}
 template <int P>
 __device__ __forceinline__ double group_sum_d(double v, int gbase, int sub)
 {
-  if constexpr (EQLB_USE_DPP && P <= 16)
+  if constexpr (EQLB_GSUM_SWIZZLE && P <= 16)
+  {
+    v += swizzle_xor_d<1>(v);
+    v += swizzle_xor_d<2>(v);
+    if constexpr (P >= 8)
+      v += swizzle_xor_d<4>(v);
+    if constexpr (P >= 16)
+      v += swizzle_xor_d<8>(v);
+    return v;
+  }
+  else if constexpr (EQLB_USE_DPP && P <= 16)
   {
     v += dpp_d<0xB1>(v); // quad_perm [1,0,3,2]
     v += dpp_d<0x4E>(v); // quad_perm [2,3,0,1]

@@ -211,7 +211,15 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   // lane index within the lane space of the bin (slots are lane-contiguous)
   const int64_t tl = (lane_index >= 0) ? lane_index : block_id * BLOCK + tid;
   const int64_t patch_local = tl / P;
-  const bool pvalid = patch_local < a.npatch;
+#ifndef EQLB_FULL_SIMPLE
+#define EQLB_FULL_SIMPLE 1 // 0: the lane predicates of the generic instance in the full-patch instance too (A/B: RT_3 0.293 against 0.300 ms, 8M triangles 2.24 against 2.29, EV RT_3 0.3285 against 0.3315)
+#endif
+#ifndef EQLB_FULL_SIMPLE_EV
+#define EQLB_FULL_SIMPLE_EV 0 // RT_2 in EV mode keeps the generic predicates (measured: 0.0844 against 0.0880 ms with the simplified ones)
+#endif
+  constexpr bool FULLS = FULL && EQLB_FULL_SIMPLE && (MODE == 0 || K >= 3 || EQLB_FULL_SIMPLE_EV);
+  // (FULL: whole wave-blocks of full patches, every lane belongs to one)
+  const bool pvalid = FULLS ? true : (patch_local < a.npatch);
   const int64_t slot = a.slot_offset + tl;
   const int64_t patch = a.patch_offset + patch_local;
 
@@ -290,11 +298,12 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   const bool interior_geo = (flag0 & PFLAG_INTERIOR) != 0;
   const int nf = interior_geo ? n : n + 1;
   const int nn = (n > 0) ? n : 1;
-  const int next = (sub + 1 < nn) ? sub + 1 : (interior_geo ? 0 : sub);
-  const int prev = (sub > 0) ? sub - 1 : (interior_geo ? nn - 1 : 0);
+  // (FULL: the P cells of the patch form a ring)
+  const int next = FULLS ? ((sub + 1) & (P - 1)) : ((sub + 1 < nn) ? sub + 1 : (interior_geo ? 0 : sub));
+  const int prev = FULLS ? ((sub + P - 1) & (P - 1)) : ((sub > 0) ? sub - 1 : (interior_geo ? nn - 1 : 0));
   const bool has_next = active && (interior_geo || sub < n - 1);
   const bool has_prev = active && (interior_geo || sub > 0);
-  const int fi_p = interior_geo ? ((sub + 1 < nn) ? sub + 1 : 0) : sub + 1;
+  const int fi_p = FULLS ? next : (interior_geo ? ((sub + 1 < nn) ? sub + 1 : 0) : sub + 1);
   const int dim = pvalid ? 1 + KB * nf + NADD * n : 0;
   (void)dim;
 
@@ -941,7 +950,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       constexpr int NC = 1 + 2 * KB; // core local unknowns [d | um | up]
       const bool fx_m = (bc0 && sub == 0) || (bcn && sub == n); // facet E_sub fixed (flux BC)
       const bool fx_p = bcn && sub == n - 1;                     // facet E_{sub+1} fixed
-      const int prevl = (sub > 0) ? sub - 1 : nn - 1;
+      const int prevl = FULLS ? prev : ((sub > 0) ? sub - 1 : nn - 1);
       const bool has_prevcell = pvalid && sub < nf && (sub > 0 || interior_geo);
 
       // (a) element system with the rows/columns of fixed (flux-BC) unknowns cleared (identity rows
@@ -1153,6 +1162,31 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       const bool in_chain = pvalid && sub >= 1 && sub < nf;
       const bool wraps = interior_geo && sub == n - 1; // coupling of E_{n-1} to E_n == E_0
       double Dp[KB][KB], Rp[KB][1 + W], OffC[KB][KB];
+#ifndef EQLB_CHAIN_MASKS
+#define EQLB_CHAIN_MASKS 1 // full-patch instances of RT_3 / RT_4: 0/1 factors instead of selects (one multiply per double instead of two v_cndmask)
+#endif
+      if constexpr (FULLS && EQLB_CHAIN_MASKS && KB >= 2)
+      {
+        // (the values are this lane's own and finite: a factor 0 is an exact zero)
+        const double mc = (sub >= 1) ? 1.0 : 0.0, mi = 1.0 - mc;          // chain row | border row (lane 0)
+        const double mo = (sub >= 1 && sub != P - 1) ? 1.0 : 0.0;         // coupling to the next chain row
+        const double m1 = (sub == 1) ? 1.0 : 0.0, mw = mc - mo;           // first | last (wrapping) chain row
+#pragma unroll
+        for (int aa = 0; aa < KB; ++aa)
+        {
+          Rp[aa][0] = mc * rr[aa];
+          Rp[aa][1] = mc * bt[aa];
+#pragma unroll
+          for (int bb = 0; bb < KB; ++bb)
+          {
+            Dp[aa][bb] = (aa == bb) ? __builtin_fma(mc, Dg[aa][bb], mi) : mc * Dg[aa][bb];
+            OffC[aa][bb] = mo * Off[aa][bb];
+            Rp[aa][2 + bb] = __builtin_fma(mw, Off[aa][bb], m1 * Off0[bb][aa]);
+          }
+        }
+      }
+      else
+      {
 #pragma unroll
       for (int aa = 0; aa < KB; ++aa)
       {
@@ -1170,6 +1204,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
             c0 += Off[aa][bb];
           Rp[aa][2 + bb] = c0;
         }
+      }
       }
       double zz[W], xs[KB];
       if constexpr (KB == 1 && P <= 16 && EQLB_CHAIN_PCR)
