@@ -153,6 +153,56 @@ __device__ __forceinline__ void ldrow16(const double* p, double (&r)[N])
   }
 }
 
+// Moments of a trace seen from the other side of a facet: y = (reversed ? B : I) x with the binomial matrix B of
+// bcoef - written as y_j = x_j + rho * sum_c (B_jc - delta_jc) x_c with rho = 1 / 0: one multiply-add per output
+// instead of a select per coefficient or per value (the partial sums of rows 1 and 2 coincide and are shared).
+// _t: the same with B^T (loads instead of unknowns).
+#ifndef EQLB_REV_FMA
+#define EQLB_REV_FMA 1
+#endif
+template <int K>
+__device__ __forceinline__ void reversal_apply(const double (&x)[K], const double rho, double (&y)[K])
+{
+#pragma unroll
+  for (int j = 0; j < K; ++j)
+  {
+    double d = 0.0;
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c <= j; ++c)
+    {
+      const double coef = bcoef(j, c) - ((j == c) ? 1.0 : 0.0);
+      if (coef != 0.0)
+      {
+        d = any ? __builtin_fma(coef, x[c], d) : coef * x[c];
+        any = true;
+      }
+    }
+    y[j] = any ? __builtin_fma(rho, d, x[j]) : x[j];
+  }
+}
+template <int K>
+__device__ __forceinline__ void reversal_apply_t(const double (&x)[K], const double rho, double (&y)[K])
+{
+#pragma unroll
+  for (int h = 0; h < K; ++h)
+  {
+    double d = 0.0;
+    bool any = false;
+#pragma unroll
+    for (int j = h; j < K; ++j)
+    {
+      const double coef = bcoef(j, h) - ((j == h) ? 1.0 : 0.0);
+      if (coef != 0.0)
+      {
+        d = any ? __builtin_fma(coef, x[j], d) : coef * x[j];
+        any = true;
+      }
+    }
+    y[h] = any ? __builtin_fma(rho, d, x[h]) : x[h];
+  }
+}
+
 template <int K, int DEG, int P, int SOLVER, int SCATTER, int BLOCK, int MODE = 0, bool FULL = false, bool INTR = false>
 __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t block_id, double* lds,
                                               const bool tables_staged = false,
@@ -261,6 +311,9 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
   const int ln = (info >> INFO_LN_SHIFT) & 3;
   const bool rev_m = (info & INFO_REV_M) != 0, rev_p = (info & INFO_REV_P) != 0;
   const int ci = active ? combo_index(fm, fp, rev_m) : 0; // row of the reduced tensors
+  const double rho_m = rev_m ? 1.0 : 0.0, rho_p = rev_p ? 1.0 : 0.0; // reversal_apply
+  (void)rho_m;
+  (void)rho_p;
 
   // ---- geometry (cached affine map) and the DG data of the cell ----
   double J00 = 1.0, J01 = 0.0, J10 = 0.0, J11 = 1.0;
@@ -512,6 +565,13 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 #pragma unroll
         for (int j = 0; j < K; ++j)
           gmn[j] = shfl_d(gm[j], gbase + next);
+#if EQLB_REV_FMA
+        double gt[K];
+        reversal_apply<K>(gmn, rho_p, gt);
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+          Jv[j] = has_next ? gpv[j] + gt[j] : 0.0;
+#else
 #pragma unroll
         for (int j = 0; j < K; ++j)
         {
@@ -526,6 +586,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
             t = gmn[j];
           Jv[j] = has_next ? gpv[j] + t : 0.0;
         }
+#endif
       }
       // zero-order chain: inclusive prefix sum of R0 + J0(previous facet)
       const double Jprev0 = shfl_d(Jv[0], gbase + prev);
@@ -628,6 +689,13 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         vprev[j] = shfl_d(mu_p[j] + Jv[j], gbase + prev);
       if (has_prev)
       {
+#if EQLB_REV_FMA
+        double vt[K];
+        reversal_apply<K>(vprev, rho_m, vt);
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+          mu_m[j] = -vt[j];
+#else
 #pragma unroll
         for (int j = 0; j < K; ++j)
         {
@@ -637,6 +705,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
             s -= (rev_m ? bcoef(j, c) : ((j == c) ? 1.0 : 0.0)) * vprev[c];
           mu_m[j] = s;
         }
+#endif
       }
       else
       {
@@ -743,6 +812,16 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
       {
         // the staged rows are those of the unreversed minus facet: [d | um] rows through B^T where it is reversed
         double lt[K];
+#if EQLB_REV_FMA
+        double lk[K];
+#pragma unroll
+        for (int h = 0; h < K; ++h)
+          lk[h] = Le[h];
+        reversal_apply_t<K>(lk, rho_m, lt);
+#pragma unroll
+        for (int h = 0; h < K; ++h)
+          Le[h] = lt[h];
+#else
 #pragma unroll
         for (int h = 0; h < K; ++h)
         {
@@ -755,6 +834,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
 #pragma unroll
         for (int h = 0; h < K; ++h)
           Le[h] = rev_m ? lt[h] : Le[h];
+#endif
       }
       if constexpr (MODE == 1)
       {
@@ -1219,7 +1299,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         double b = Dp[0][0], r0 = Rp[0][0], r1 = Rp[0][1], r2 = Rp[0][2];
         const double B1 = Rp[0][1], B2 = Rp[0][2];
         double am = dpp_d<0x111>(OffC[0][0]);
-        if (sub == 0)
+        if (!(FULLS && EQLB_CHAIN_MASKS) && sub == 0) // (full patches: what lane 0 receives is the zero of a wrapping row)
           am = 0.0;
         bool posdef = true; // pivots of the levels, of the last level and of the border system
 #define EQLB_PCR_LEVEL(S)                                                                          \
@@ -1344,7 +1424,9 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
             for (int e = 0; e < KB; ++e)
             {
               const double v = dpp_d<0x111>(OffC[e][aa]); // A_i = OffC_{i-1}^T
-              A[aa][e] = (sub == 0) ? 0.0 : v;
+              // (full-patch instance: the lane before lane 0 is the wrapping row of the previous patch of the wave-block,
+              // whose OffC is zero, or lies outside the row)
+              A[aa][e] = (FULLS && EQLB_CHAIN_MASKS) ? v : ((sub == 0) ? 0.0 : v);
             }
   #pragma unroll
             for (int c = 0; c < 1 + W; ++c)
@@ -1641,6 +1723,19 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
     {
       // own-frame moments: mu_m -= Bm [d; um], mu_p += [d; up]
       double ym[K], yp[K];
+#if EQLB_REV_FMA
+      double uk[K], ut[K];
+#pragma unroll
+      for (int c = 0; c < K; ++c)
+        uk[c] = ul[c]; // ul[0] = d, ul[1..KB] = um
+      reversal_apply<K>(uk, rho_m, ut);
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+      {
+        ym[j] = mu_m[j] - ut[j];
+        yp[j] = mu_p[j] + ((j == 0) ? ul[0] : ul[KB + j]);
+      }
+#else
 #pragma unroll
       for (int j = 0; j < K; ++j)
       {
@@ -1651,6 +1746,7 @@ __device__ __forceinline__ void se_patch_body(const SeArgs& a, const int64_t blo
         ym[j] = s;
         yp[j] = mu_p[j] + ((j == 0) ? ul[0] : ul[KB + j]);
       }
+#endif
       if constexpr (SCATTER == 2)
       {
         // tiled launch: the row goes to the LDS slot of the owned cell (halo lanes drop it); the two

@@ -175,6 +175,53 @@ __device__ __forceinline__ void pcr_apply(double (&r)[NC], const PcrMult<P>& m)
     r[c] *= m.ibf;
 }
 
+// ---- the same for the columns of B_k in ROTATED storage (full interior patches: P chain / border rows, P ring points) --
+// B_k couples row E_i to the ring points i - 1, i, i + 1 (cyclic).  Stored by ring point, its P columns have their
+// three entries in different registers in every lane (a chain of selects per column to build them, and no way
+// for the compiler to skip the zeros).  Stored by OFFSET - entry d of lane i belongs to ring point (i + d) mod P -
+// the three entries sit in the registers 0, 1, P - 1 of every lane, a level of the reduction with stride s reads
+// offset d + s from the lane s below and d - s from the lane s above (register indices fixed at compile time), and
+// the zeros are known: offsets farther than 2^l from 0 are still zero before level l.
+#ifndef EQLB_STRESS_ROTATED
+#define EQLB_STRESS_ROTATED 1
+#endif
+__host__ __device__ constexpr bool rot_nz(int P, int L, int d)
+{
+  const int dd = ((d % P) + P) % P, dist = (dd < P - dd) ? dd : P - dd;
+  return dist <= (1 << L);
+}
+template <int P, int S, int L>
+__device__ __forceinline__ void pcr_apply_level_rot(double (&r)[P], const PcrMult<P>& m)
+{
+  if constexpr (P > S)
+  {
+    double n[P];
+#pragma unroll
+    for (int d = 0; d < P; ++d)
+    {
+      double v = rot_nz(P, L, d) ? r[d] : 0.0;
+      if (rot_nz(P, L, d + S))
+        v = __builtin_fma(-m.al[L], dpp_d<0x110 + S>(r[(d + S) % P]), v);
+      if (rot_nz(P, L, d - S))
+        v = __builtin_fma(-m.ga[L], dpp_d<0x100 + S>(r[(d - S + P) % P]), v);
+      n[d] = v;
+    }
+#pragma unroll
+    for (int d = 0; d < P; ++d)
+      r[d] = n[d];
+  }
+}
+template <int P>
+__device__ __forceinline__ void pcr_apply_rot(double (&r)[P], const PcrMult<P>& m)
+{
+  pcr_apply_level_rot<P, 1, 0>(r, m);
+  pcr_apply_level_rot<P, 2, 1>(r, m);
+  pcr_apply_level_rot<P, 4, 2>(r, m);
+#pragma unroll
+  for (int d = 0; d < P; ++d)
+    r[d] *= m.ibf;
+}
+
 // ---- the patch body ------------------------------------------------------------------------------------
 // lds: F | H | D | TE | WQ | HB (as k_se_patch_tiled) | V | VQ
 template <int P, bool FULL>
@@ -632,7 +679,22 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
     build_B(k, ci, (k == 0) ? J10 : -J00, (k == 0) ? J11 : -J01, Brow[k], bcn[k], Bd[k], Bdc[k]);
     // columns of B_k through the chain reduction: ring points, and the patch node on boundary patches
     constexpr int NCEN = FULL ? 0 : 1;
+    constexpr bool ROT = FULL && EQLB_STRESS_ROTATED;
     double col[P + NCEN];
+    if constexpr (ROT)
+    {
+      // rotated storage (pcr_apply_rot): entry d = ring point (sub + d) mod P; lane 0 is no chain row
+      const double mch = in_chain ? 1.0 : 0.0;
+#pragma unroll
+      for (int d = 0; d < P; ++d)
+        col[d] = 0.0;
+      col[0] = mch * Brow[k][1];
+      col[1] = mch * Brow[k][2];
+      col[P - 1] = mch * Brow[k][0];
+      pcr_apply_rot<P>(col, mult);
+    }
+    else
+    {
 #pragma unroll
     for (int c = 0; c < P; ++c)
     {
@@ -642,6 +704,7 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
     if constexpr (!FULL)
       col[P] = in_chain ? bcn[k] : 0.0;
     pcr_apply<P, P + NCEN>(col, mult);
+    }
     // border part of every column, in the lane of its ring point: q^(c) = b_border - C^T A_c^-1 b_chain with
     // the sparse original column (rows c-1, c, c+1; lane 0 is no chain row: s1 = s2 = 0 there, so the wrap
     // nf - 1 -> ring point 0 is the only cyclic term)
@@ -658,6 +721,24 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
       z0 = Zi00 * q0 + Zi01 * q1;
       z1 = Zi01 * q0 + Zi11 * q1;
     }
+    if constexpr (ROT)
+    {
+      // rv[1 + d] collects S[sub][(sub + d) mod P] here (turned into ring-point order behind the loop over k):
+      // the row before this lane holds that column at offset d + 1, the row after it at offset d - 1
+#pragma unroll
+      for (int d = 0; d < P; ++d)
+      {
+        double v = Brow[k][1] * col[d];
+        v += ring_prev(Brow[k][2] * col[(d + 1) % P]);
+        v += ring_next_nc(Brow[k][0] * col[(d + P - 1) % P]);
+        const int src = gbase + ((sub + d) & (P - 1));
+        v = __builtin_fma(q1, from_lane(z1, src), __builtin_fma(q0, from_lane(z0, src), v));
+        asm volatile("" : "+v"(v)); // keeps the exchanges of the columns apart (register pressure)
+        rv[1 + d] += v;
+      }
+    }
+    else
+    {
 #pragma unroll
     for (int c = 0; c < P; ++c)
     {
@@ -671,6 +752,7 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
       asm volatile("" : "+v"(v)); // keeps the exchanges of the columns apart (register pressure)
       rv[1 + c] += v;
     }
+    }
     if constexpr (!FULL)
     {
       // the patch node (needed on boundary patches): dense column, all rows E_i carry bcn_i
@@ -681,6 +763,22 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
       const double tn = col[P];
       rv[0] += Brow[k][1] * tn + ring_prev(Brow[k][2] * tn) + ring_next_nc(Brow[k][0] * tn) + q0 * zn0 + q1 * zn1;
       rn[0] += group_sum_d<P>(bch * tn, gbase, sub) + qn0 * zn0 + qn1 * zn1;
+    }
+  }
+  if constexpr (FULL && EQLB_STRESS_ROTATED)
+  {
+    // S[sub][c] = rotated[(c - sub) mod P]: a rotation of the P registers by `sub`, one conditional step per bit
+#pragma unroll
+    for (int st = 1; st < P; st <<= 1)
+    {
+      const bool bit = (sub & st) != 0;
+      double t_[P];
+#pragma unroll
+      for (int c = 0; c < P; ++c)
+        t_[c] = bit ? rv[1 + (c - st + P) % P] : rv[1 + c];
+#pragma unroll
+      for (int c = 0; c < P; ++c)
+        rv[1 + c] = t_[c];
     }
   }
   if constexpr (!FULL)
