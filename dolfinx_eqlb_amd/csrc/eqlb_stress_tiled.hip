@@ -830,6 +830,38 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
       for (int c = 1; c <= NPT; ++c)
         rv[c] -= f * rn[c];
     }
+#ifndef EQLB_STRESS_GJ
+#define EQLB_STRESS_GJ 1
+#endif
+    if constexpr (FULL && EQLB_STRESS_GJ)
+    {
+      // Gauss-Jordan: the rows ABOVE the pivot are lanes that execute the row update anyway (their factor was a
+      // forced zero), so eliminating there as well costs no instruction - and leaves every lane with its own
+      // diagonal entry only: no back substitution, i.e. no second chain of eight dependent broadcasts and
+      // reciprocals.  (Full interior patches: the node multiplier is fixed to zero above, rn = e_0.)
+      double dinv = 1.0;
+#pragma unroll
+      for (int p = 1; p < NPT; ++p)
+      {
+        double pr[NPT + 1];
+#pragma unroll
+        for (int c = p; c <= NPT; ++c)
+          pr[c] = from_lane(rv[c], gbase + p - 1);
+        if (!(pr[p] > 0.0))
+          sing = 1;
+        const double ip = rcp_d(pr[p]);
+        const bool own = sub + 1 == p;
+        const double f = own ? 0.0 : rv[p] * ip;
+        dinv = own ? ip : dinv;
+#pragma unroll
+        for (int c = p + 1; c <= NPT; ++c)
+          rv[c] -= f * pr[c];
+      }
+      gam_own = rv[NPT] * dinv;
+      gam0 = rn[NPT] * rcp_d(rn[0]);
+    }
+    else
+    {
     double gam[NPT];
 #pragma unroll
     for (int p = 1; p < NPT; ++p)
@@ -864,6 +896,7 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
       for (int c = 1; c < NPT; ++c)
         t -= rn[c] * gam[c];
       gam0 = t * rcp_d(rn[0]);
+    }
     }
     if (meanvalue)
     {
