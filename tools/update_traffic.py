@@ -13,7 +13,7 @@ CSRC = os.path.join(ROOT, "dolfinx_eqlb_amd", "csrc")
 ENTRIES = {  # traffic.json key: (pmc summary, source file, note)
     "k_se_patch_tiled<K=2>": ("r03_headline_pmc.csv", "eqlb_se_kernels.hip", ""),
     "k_se_patch_tiled<K=3>": ("r03_k3_pmc.csv", "eqlb_se_kernels.hip", ""),
-    "k_se_stress_tiled": ("r03_stress_pmc.csv", "eqlb_stress_tiled.hip", "fused kernel only, full patches; "),
+    "k_se_stress_tiled": ("r03_stress_pmc.csv", "eqlb_stress_tiled.hip", "fused kernel only - full patches; "),
 }
 
 
