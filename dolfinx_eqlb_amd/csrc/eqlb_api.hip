@@ -118,6 +118,7 @@ void free_boundary(eqlb_se* h)
   dfree(h->t_pn);
   dfree(h->t_pflag);
   h->ntiles = 0;
+  h->t_mixed = false;
   h->boundary_set = false;
 }
 // Grouped boundary patches of the stress path (se/reconstruction.hpp:170-234, se/Patch.cpp:60-104,
@@ -555,11 +556,13 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
                 bool full_only = false)
 {
   // nodes of bins >= max_bin are left out (like masked-out nodes): another path equilibrates them.
-  // full_only (fused stress launch): so are all patches that are not FULL (interior, as many cells as lanes);
-  // the lists of a tile are padded to whole wave-blocks with copies of a full patch that own no cell
+  // full_only (fused stress launch on the crossed benchmark meshes): so are all patches that are not FULL (interior,
+  // as many cells as lanes); the lists of a tile are padded to whole wave-blocks with copies of a full patch that
+  // own no cell
   const eqlb::DeviceMesh& m = h->mesh->m;
   const int32_t nc = m.ncells;
   std::vector<int8_t> node_bin(node_bin_all);
+  std::vector<uint8_t> is_rest(max_bin < eqlb::MAX_BINS ? m.nnodes : 0, 0);
   h->t_rest = 0;
   for (int32_t i = 0; i < m.nnodes; ++i)
   {
@@ -571,11 +574,13 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
     {
       b = -1;
       ++h->t_rest;
+      if (!is_rest.empty())
+        is_rest[i] = 1;
     }
   }
   dfree(h->rest_cells);
   h->nrest_cells = 0;
-  if (full_only && h->t_rest > 0)
+  if (!is_rest.empty() && h->t_rest > 0)
   {
     // cells with a vertex whose patch the generic kernels take: the compact reduction of their slot rows
     std::vector<int32_t> rc;
@@ -583,7 +588,7 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
       for (int j = 0; j < 3; ++j)
       {
         const int32_t nd = m.h_cell_nodes[3 * (size_t)c + j];
-        if (node_bin_all[nd] >= 0 && node_bin[nd] < 0)
+        if (is_rest[nd])
         {
           rc.push_back(c);
           break;
@@ -1350,7 +1355,30 @@ try
   if (h->t_stress || (!h->stress && h->k <= 3))
   {
     // fused stress launch: its own tile size, patches of up to 8 facets (bins 0, 1)
-    const int stt = h->t_stress ? build_tiles(h, node_bin, a, eqlb::stress_tile_cells(), 2, true) : build_tiles(h, node_bin, a);
+    h->t_mixed = false;
+    if (h->t_stress)
+    {
+      // Patches of the bins 0, 1 that are not full (interior with fewer cells than lanes, boundary): on the crossed
+      // benchmark meshes the boundary patches only (0.4 %) - the tiles list the full patches and the others go with
+      // the rest (generic kernels on a side stream next to the fused kernel); on unstructured meshes most patches -
+      // the tiles list every patch of the two bins and the kernel carries both instances of the body.
+      // EQLB_STRESS_MIXED_TILES=0/1 forces the choice.
+      int64_t nlisted = 0, nnotfull = 0;
+      for (int32_t i = 0; i < m.nnodes; ++i)
+      {
+        const int8_t b = node_bin[i];
+        if (b < 0 || b >= 2)
+          continue;
+        ++nlisted;
+        if (!(m.h_node_ncells[i] == m.h_node_nfcts[i] && m.h_node_ncells[i] == eqlb::BIN_P[b]))
+          ++nnotfull;
+      }
+      h->t_mixed = nnotfull * 20 > nlisted;
+      if (const char* env = getenv("EQLB_STRESS_MIXED_TILES"))
+        h->t_mixed = env[0] != '0';
+    }
+    const int stt = h->t_stress ? build_tiles(h, node_bin, a, eqlb::stress_tile_cells(), 2, !h->t_mixed)
+                                : build_tiles(h, node_bin, a);
     if (stt)
       return stt;
     if (h->mode == 1)
@@ -1658,8 +1686,8 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
   auto run_slot_path = [&](int first_bin, int accumulate) -> int {
     const bool rest = first_bin < 0;
     auto bin_np = [&](int b) -> int64_t {
-      if (rest)
-        return h->bins[b].npatch - ((b < 2) ? h->bins[b].nfull : 0);
+      if (rest) // (tiles with every patch of the bins 0, 1: the higher bins only)
+        return (b < 2) ? (h->t_mixed ? 0 : h->bins[b].npatch - h->bins[b].nfull) : h->bins[b].npatch;
       return (b >= first_bin) ? h->bins[b].npatch : 0;
     };
     auto bin_po = [&](int b) -> int64_t { return h->bins[b].patch_offset + ((rest && b < 2) ? h->bins[b].nfull : 0); };
@@ -1820,10 +1848,18 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
       HIP_TRY(hipEventRecord(evs[0], stream));
     int r0 = 0;
     // the rest of a fused stress launch (boundary patches, interior patches that are not full, bins of more than 8
-    // lanes; with the last range of tiles of a two-phase sweep): its patch kernels - a handful of small launches,
-    // 50 us back to back at 1M triangles - run on a side stream NEXT TO the fused kernel, their sums are added
-    // behind it
-    const bool rest_now = stress_fused && h->t_rest > 0 && h->tile_first + tcount == h->ntiles;
+    // lanes): its patch kernels - a handful of small launches, 50 us back to back at 1M triangles - run on a side
+    // stream NEXT TO the fused kernel, their sums are added behind it.  With the FIRST range of tiles of a two-phase
+    // sweep: its patches touch ghost cells like any other, and the caller packs the ghost rows behind that range
+    // (option accumulate = 0: the tiled launches STORE, the rest can only be added behind the last of them; an empty
+    // range - a rank without priority tiles, or with priority tiles only - takes nothing along)
+    const bool with_first_range = tcount > 0 && (h->accumulate ? h->tile_first == 0 : h->tile_first + tcount == h->ntiles);
+    const bool rest_now = stress_fused && h->t_rest > 0
+#ifdef EQLB_EXP_REST_LAST // (the order before the fix, to show that tests/test_gpu_halo.py sees it)
+                          && (h->tile_first + tcount == h->ntiles);
+#else
+                          && with_first_range;
+#endif
     if (rest_now)
     {
       if (!h->side_stream)
@@ -1850,7 +1886,7 @@ static int equilibrate_lists(eqlb_se_t* h, const double* const* g_in, const doub
     {
       // rows 0, 1 of the stress and their weak symmetry in one launch
       select_rhs(at, 0, false);
-      const int st = eqlb::launch_se_stress_tiled(at, ta, d_g.data(), d_f.data(), d_x.data(), stream);
+      const int st = eqlb::launch_se_stress_tiled(at, ta, d_g.data(), d_f.data(), d_x.data(), stream, h->t_mixed);
       if (st)
         return fail(st, "fused stress kernel launch failed");
       r0 = 2;

@@ -193,8 +193,10 @@ int tile_cells_ev_of(int k);
 int tile_cells_max_of(int k);
 int launch_se_weaksym(int k, int P, bool no_flux_bcs, const SeArgs& a, hipStream_t stream);
 // fused stress launch (RT_2, no stress flux BCs, patches of up to 8 facets): rows 0, 1 + weak symmetry
+// mixed: tile lists with every patch of up to 8 lanes (full ones first; generic instance of the body for the others),
+// else lists of full patches only
 int launch_se_stress_tiled(const SeArgs& a, const TileArgs& t, const double* const* g, const double* const* f,
-                           double* const* x, hipStream_t stream);
+                           double* const* x, hipStream_t stream, bool mixed = false);
 int stress_tile_cells();
 int launch_ev_patch_fused(int k, const SeArgs& a, const FusedBins& fb, hipStream_t stream);
 // conforming <-> broken layout of the EV equilibrator (eqlb_ev.hip); cell_dofs may be nullptr
@@ -305,6 +307,9 @@ struct eqlb_se
   int32_t *t_tile_cells = nullptr, *t_slot_cell = nullptr, *t_facet_owner = nullptr;
   uint32_t* t_slot_info = nullptr;
   uint8_t *t_pn = nullptr, *t_pflag = nullptr;
+  // fused stress launch: the tiles list EVERY patch of the bins 0, 1 (full ones first), not the full ones only - where
+  // the others are more than a few per cent of the patches (unstructured meshes); kernel with both instances
+  bool t_mixed = false;
   // two-phase sweeps (multi-GPU overlap): tiles owning a priority cell are numbered first
   std::vector<int32_t> prio_cells;
   int32_t t_nprio = 0;              // number of priority tiles

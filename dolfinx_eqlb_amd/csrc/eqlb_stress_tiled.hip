@@ -833,7 +833,7 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
 #ifndef EQLB_STRESS_GJ
 #define EQLB_STRESS_GJ 1
 #endif
-    if constexpr (FULL && EQLB_STRESS_GJ)
+    if constexpr (EQLB_STRESS_GJ)
     {
       // Gauss-Jordan: the rows ABOVE the pivot are lanes that execute the row update anyway (their factor was a
       // forced zero), so eliminating there as well costs no instruction - and leaves every lane with its own
@@ -858,7 +858,18 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
           rv[c] -= f * pr[c];
       }
       gam_own = rv[NPT] * dinv;
-      gam0 = rn[NPT] * rcp_d(rn[0]);
+      if constexpr (FULL)
+        gam0 = rn[NPT] * rcp_d(rn[0]);
+      else
+      {
+        // node row (boundary patches: a multiplier of its own): the ring multipliers are all known at once - eight
+        // independent broadcasts, no chain
+        double t = rn[NPT];
+#pragma unroll
+        for (int c = 1; c < NPT; ++c)
+          t -= rn[c] * from_lane(gam_own, gbase + c - 1);
+        gam0 = t * rcp_d(rn[0]);
+      }
     }
     else
     {
@@ -1008,6 +1019,13 @@ __device__ __forceinline__ int xcd_remap2(int b, int n)
 constexpr int STRESS_TCMAX = EQLB_STRESS_TILE_CELLS;
 } // namespace
 
+// MIXED = false: the tile lists hold full patches only (the specialised instance of the body: 0 B of scratch) - the
+// crossed benchmark meshes, where everything else is 0.4 % of the patches and goes with the rest.  MIXED = true: the
+// tile lists hold every patch of up to 8 lanes, the full ones first; whole wave-blocks of full patches run the
+// specialised instance, the others the generic one (interior patches with fewer cells than lanes, boundary patches
+// without stress flux BCs).  The spills of the generic instance cost every wave of the kernel they are in, which is
+// why the two kernels exist: on unstructured meshes (valence 5 - 7 in groups of 8 lanes) most patches are generic.
+template <bool MIXED>
 __global__ void __launch_bounds__(EQLB_STRESS_THREADS, EQLB_STRESS_WAVES)
 k_se_stress_tiled(const SeArgs a0, const TileArgs ta, const StressRows rows)
 {
@@ -1041,12 +1059,18 @@ k_se_stress_tiled(const SeArgs a0, const TileArgs ta, const StressRows rows)
        registers more than there are and the scratch it brings slows every wave of the kernel; those \
        patches run on the generic kernels (slot path) in the same call */                           \
     const int np = td.npatch[B];                                                                    \
-    const int nwb = (np * PP) >> 6;                                                                 \
+    const int nwb = MIXED ? ((np * PP + 63) >> 6) : ((np * PP) >> 6);                               \
     a.npatch = np;                                                                                  \
     a.slot_offset = td.slot_start[B];                                                               \
     a.patch_offset = td.patch_start[B];                                                             \
-    for (; u < nwb; u += NW)                                                                        \
+    const int nwb_full = MIXED ? ((td.nfull[B] * PP) >> 6) : nwb;                                   \
+    /* two loops, not one loop with a branch: the register allocation of the full-patch instance (no spills \
+       on its own) is then not tied to the generic one (same wave-block -> wave assignment) */         \
+    for (; u < nwb_full; u += NW)                                                                   \
       stress_patch_body<PP, true>(a, rows, lds, (int64_t)u * 64 + lane, sSlots, TC);                \
+    if constexpr (MIXED)                                                                            \
+      for (; u < nwb; u += NW)                                                                      \
+        stress_patch_body<PP, false>(a, rows, lds, (int64_t)u * 64 + lane, sSlots, TC);             \
     u -= nwb;                                                                                       \
   }
   EQLB_STRESS_BIN(0, 4)
@@ -1095,7 +1119,7 @@ k_se_stress_tiled(const SeArgs a0, const TileArgs ta, const StressRows rows)
 int stress_tile_cells() { return STRESS_TCMAX; }
 
 int launch_se_stress_tiled(const SeArgs& a, const TileArgs& t, const double* const* g, const double* const* f,
-                           double* const* x, hipStream_t stream)
+                           double* const* x, hipStream_t stream, bool mixed)
 {
   using Z = Sizes<2, 1, 8>;
   if (t.tc < 1 || t.tc > STRESS_TCMAX)
@@ -1106,16 +1130,22 @@ int launch_se_stress_tiled(const SeArgs& a, const TileArgs& t, const double* con
   static bool attr_set = false;
   if (!attr_set)
   {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_se_stress_tiled),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_se_stress_tiled<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess
+        || hipFuncSetAttribute(reinterpret_cast<const void*>(k_se_stress_tiled<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return EQLB_ERR_DEVICE;
     attr_set = true;
   }
   if (t.ntiles == 0)
     return 0;
   StressRows rows{{g[0], g[1]}, {f[0], f[1]}, {x[0], x[1]}};
-  hipLaunchKernelGGL(k_se_stress_tiled, dim3((unsigned)t.ntiles), dim3(EQLB_STRESS_THREADS), lds_bytes, stream, a,
-                     t, rows);
+  if (!mixed)
+    hipLaunchKernelGGL(k_se_stress_tiled<false>, dim3((unsigned)t.ntiles), dim3(EQLB_STRESS_THREADS), lds_bytes, stream,
+                       a, t, rows);
+  else
+    hipLaunchKernelGGL(k_se_stress_tiled<true>, dim3((unsigned)t.ntiles), dim3(EQLB_STRESS_THREADS), lds_bytes, stream,
+                       a, t, rows);
   return (hipGetLastError() == hipSuccess) ? 0 : EQLB_ERR_DEVICE;
 }
 

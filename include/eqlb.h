@@ -232,7 +232,10 @@ int eqlb_get_reference_table(int32_t k, int32_t degree_dg, const char* name, dou
  * neighbour rank waits for - make their tiles the FIRST tiles; eqlb_se_num_priority_tiles returns how
  * many there are.  With the options "tile_first" / "tile_count" (eqlb_se_set_option; count -1 = to the
  * end) an equilibrate call sweeps a range of tiles only: first the priority tiles, then - while the
- * halo exchange of their rows is in flight - the rest.  Tiled scatter only. */
+ * halo exchange of their rows is in flight - the rest.  Tiled scatter only.  Stress equilibration: the patches the
+ * fused stress kernel does not take (boundary patches, patches that are not full) are equilibrated by the call whose
+ * range starts at tile 0, so that the ghost rows are complete behind the first range (option "accumulate" = 1, the
+ * default; with accumulate = 0 the tiled launches store and those patches follow the last range). */
 int eqlb_se_set_priority_cells(eqlb_se_t* handle, const int32_t* cells, int32_t n);
 int32_t eqlb_se_num_priority_tiles(const eqlb_se_t* handle);
 /* eqlb_se_equilibrate on device memory for the tiles [tile_first, tile_first + tile_count) only

@@ -176,14 +176,18 @@ def test_two_phase_sweep_with_halo_between(oracle_mod):
         assert np.abs(got - ref).max() <= 1e-10 * np.abs(gref).max()
 
 
-def test_halo_exchange_class_on_device_with_side_stream_transport(oracle_mod, monkeypatch):
+@pytest.mark.parametrize("stress", [False, True])
+def test_halo_exchange_class_on_device_with_side_stream_transport(oracle_mod, monkeypatch, stress):
     """HaloExchange.start / finish themselves (not the bare halo kernels) on CUDA tensors: three strips
     on one device, two accumulating two-phase steps.  RCCL is replaced by a stand-in with the stream
     semantics of the NCCL backend: batch_isend_irecv enqueues the copies on a SIDE stream that waits
     for the caller's current stream, wait() makes the current stream wait for the side stream.  That
     exercises what the gloo tests cannot: the ordering of the ctypes-launched pack / unpack kernels
     (raw stream handle) against the transport stream, the re-use of the cached P2POp list and of the
-    persistent send / receive buffers across steps, and the clearing of the ghost rows."""
+    persistent send / receive buffers across steps, and the clearing of the ghost rows.
+    stress: two stress rows + weak symmetry in the two-phase sweep - the patches the fused stress kernel
+    does not take (boundary patches: generic kernels) touch ghost cells as well and have to be complete
+    before the rows are packed, i.e. run with the FIRST range of tiles."""
     import torch
     import torch.distributed as dist
     from dolfinx_eqlb_amd import cpp
@@ -222,20 +226,28 @@ def test_halo_exchange_class_on_device_with_side_stream_transport(oracle_mod, mo
 
     gmesh = create_rectangle(world * n, n, 0.0, float(world))
     gft = facet_types(gmesh)
-    gG, gf = make_compatible_data(gmesh, k, gft, seed=5)
-    gref = oracle_mod.se_reconstruct(gmesh, k, gft, gG[None], gf[None])[0].reshape(gmesh.ncells, nrt)
+    R = 2 if stress else 1
+    if stress:
+        from synthetic import make_compatible_stress_data
+        gft = np.repeat(gft, 2, axis=0)
+        gG, gf = make_compatible_stress_data(gmesh, k, gft)
+        gref = oracle_mod.se_reconstruct(gmesh, k, gft, gG, gf, stress=True).reshape(R, gmesh.ncells, nrt)
+    else:
+        gG, gf = make_compatible_data(gmesh, k, gft, seed=5)
+        gG, gf = gG[None], gf[None]
+        gref = oracle_mod.se_reconstruct(gmesh, k, gft, gG, gf).reshape(R, gmesh.ncells, nrt)
     ranks = []
     for rank in range(world):
         part = dd.StripPartition(n, rank, world)
         gi, gj, gt = part.grid_ids
         gcell = (gj * (world * n) + gi + rank * n) * 4 + gt
-        eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(part.mesh), k, 1)
+        eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(part.mesh), k, R, reconstruct_stress=stress)
         eq.set_priority_cells(part.send_cells)
-        eq.set_boundary(part.facet_types(), node_mask=part.node_mask)
-        ranks.append(dict(part=part, gcell=gcell, eq=eq, halo=dd.HaloExchange(part, nrt, dev, 1),
-                          G=torch.from_numpy(gG.reshape(gmesh.ncells, -1)[gcell].ravel()).to(dev),
-                          f=torch.from_numpy(gf.reshape(gmesh.ncells, -1)[gcell].ravel()).to(dev),
-                          x=torch.zeros(part.mesh.ncells * nrt, dtype=torch.float64, device=dev)))
+        eq.set_boundary(part.facet_types(R), node_mask=part.node_mask)
+        ranks.append(dict(part=part, gcell=gcell, eq=eq, halo=dd.HaloExchange(part, nrt, dev, R),
+                          G=torch.from_numpy(np.ascontiguousarray(gG.reshape(R, gmesh.ncells, -1)[:, gcell]).ravel()).to(dev),
+                          f=torch.from_numpy(np.ascontiguousarray(gf.reshape(R, gmesh.ncells, -1)[:, gcell]).ravel()).to(dev),
+                          x=torch.zeros(R * part.mesh.ncells * nrt, dtype=torch.float64, device=dev)))
     stream = torch.cuda.current_stream().cuda_stream
     for step in range(nsteps):
         for rank, r in enumerate(ranks):  # ascending: the send of rank - 1 is in flight when rank receives
@@ -249,11 +261,11 @@ def test_halo_exchange_class_on_device_with_side_stream_transport(oracle_mod, mo
     assert not mailbox
     for r in ranks:
         part = r["part"]
-        x = r["x"].cpu().numpy().reshape(part.mesh.ncells, nrt)
-        ref = nsteps * gref[r["gcell"][part.cell_owned]]
-        assert np.abs(x[part.cell_owned] - ref).max() <= 1e-10 * nsteps * np.abs(gref).max()
+        x = r["x"].cpu().numpy().reshape(R, part.mesh.ncells, nrt)
+        ref = nsteps * gref[:, r["gcell"][part.cell_owned]]
+        assert np.abs(x[:, part.cell_owned] - ref).max() <= 1e-10 * nsteps * np.abs(gref).max()
         if part.send_cells.size:
-            assert np.all(x[part.send_cells] == 0.0)  # ghost rows cleared after packing
+            assert np.all(x[:, part.send_cells] == 0.0)  # ghost rows cleared after packing
 
 
 def test_rccl_transport_self_send_on_one_device():

@@ -277,3 +277,46 @@ def test_stress_boundary_layouts(mesh_name, k, id_bc):
     assert asym < 1e-11
     assert chk.check_weak_symmetry_condition(mesh, k, x)
     assert dev <= 1e-9
+
+
+@pytest.mark.parametrize("mesh_kind", ["delaunay", "square"])
+def test_mixed_stress_tiles_on_and_off(oracle_mod, monkeypatch, mesh_kind):
+    """Fused stress launch: the patches of up to 8 lanes that are not full (interior with 3, 5 - 7 cells, boundary
+    patches) either in the tile lists next to the full ones (kernel with both instances of the body;
+    EQLB_STRESS_MIXED_TILES=1: the default where they are more than 5 % of the patches - unstructured and small
+    meshes) or with the rest through the slot buffer (=0: tile lists of full patches only, the default on the crossed
+    benchmark meshes).  Both against the oracle, twice on the same handle, with += and with = semantics, and with a
+    plain flux riding along as third right-hand side."""
+    from dolfinx_eqlb_amd import cpp
+    from dolfinx_eqlb_amd.mesh import create_unit_square
+    from synthetic import facet_types, make_compatible_data, make_compatible_stress_data
+    k = 2
+    if mesh_kind == "delaunay":
+        from test_gpu_unstructured import delaunay_mesh
+        mesh = delaunay_mesh(1500, seed=3)
+    else:
+        mesh = create_unit_square(18, shuffle_seed=5, perturb=0.2)
+    ft1 = facet_types(mesh, None)
+    ft = np.repeat(ft1, 3, axis=0)
+    G2, f2 = make_compatible_stress_data(mesh, k, ft[:2])
+    G3, f3 = make_compatible_data(mesh, k, ft1, seed=99)
+    G, f = np.concatenate([G2, G3[None]]), np.concatenate([f2, f3[None]])
+    ref = np.concatenate([oracle_mod.se_reconstruct(mesh, k, ft[:2], G2, f2, stress=True),
+                          oracle_mod.se_reconstruct(mesh, k, ft1, G3[None], f3[None])])
+    info = {}
+    for mode in ("0", "1", None):
+        if mode is None:
+            monkeypatch.delenv("EQLB_STRESS_MIXED_TILES", raising=False)
+        else:
+            monkeypatch.setenv("EQLB_STRESS_MIXED_TILES", mode)
+        eq = cpp.SemiExplicitEquilibrator(cpp.DeviceMesh(mesh), k, 3, reconstruct_stress=True)
+        eq.set_boundary(ft)
+        info[mode] = eq.tiling_info()["patch_instances"]
+        for _ in range(2):
+            x = eq.equilibrate_host(G, f)
+            assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max(), mode
+        eq.set_option("accumulate", 0)
+        x = eq.equilibrate_host(G, f, flux_hdiv=np.full_like(ref, 7.0))
+        assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max(), mode
+    assert info["1"] != info["0"]       # every patch of up to 8 lanes | full patches, padded to whole wave-blocks
+    assert info[None] == info["1"]      # both meshes: more than 5 % of the patches are not full
