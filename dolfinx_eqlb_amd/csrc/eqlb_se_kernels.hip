@@ -2112,6 +2112,9 @@ __device__ __forceinline__ void tile_sweep_flush(const SeArgs& a0, const TileArg
 #ifndef EQLB_TILE_INTERIOR
 #define EQLB_TILE_INTERIOR 1
 #endif
+#ifndef EQLB_TILE_INTERIOR_K3
+#define EQLB_TILE_INTERIOR_K3 0 // the interior-patch instance for RT_3 as well: no gain on the Delaunay mesh (0.413 - 0.418 ms either way)
+#endif
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int NW = TILE_THREADS / 64;
   int u = wave;
@@ -2127,7 +2130,7 @@ __device__ __forceinline__ void tile_sweep_flush(const SeArgs& a0, const TileArg
     constexpr bool SPEC = PP <= 8 && K >= 2;                                                        \
     const int nwb_full = SPEC ? ((td.nfull[B] * PP) >> 6) : 0;                                      \
     /* wave-blocks of interior patches of any size (the patches behind the full ones; K = 2, P = 8, 16) */ \
-    constexpr bool SPECI = EQLB_TILE_INTERIOR && K == 2 && (PP == 8 || PP == 16);                   \
+    constexpr bool SPECI = EQLB_TILE_INTERIOR && ((K == 2 && (PP == 8 || PP == 16)) || (EQLB_TILE_INTERIOR_K3 && K == 3 && PP == 8)); \
     const int nwb_int = SPECI ? ((td.nint[B] * PP) >> 6) : 0;                                       \
     for (; u < nwb; u += NW)                                                                        \
     {                                                                                               \
