@@ -757,7 +757,8 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
   // first -, in order of first appearance; flat storage, 3 TC entries per tile
   constexpr int NB = eqlb::MAX_BINS;
   uvec<int32_t> tnodes((size_t)ntiles * 3 * TC);
-  std::vector<int32_t> tcount((size_t)ntiles * 3 * NB, 0); // [tile][bin][full, interior, other]
+  constexpr int NCL = 6; // classes of a bin: full | interior with P - 1, P - 2, P - 3 cells | other interior | boundary
+  std::vector<int32_t> tcount((size_t)ntiles * NCL * NB, 0); // [tile][bin][class]
   auto tile_chunks = [&](auto work) {
     const int64_t nt = host_workers(ntiles / 32);
     if (nt <= 1)
@@ -770,7 +771,8 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
       wk.spawn([&work, ntiles, w, nt]() { work((int64_t)ntiles * w / nt, (int64_t)ntiles * (w + 1) / nt); });
     wk.join();
   };
-  // sort key of a node: 3 * bin + (full interior patch 0 | other interior patch 1 | boundary patch 2); -1: not listed
+  // sort key of a node: NCL * bin + class (full interior patch 0 | interior patch with P - 1, P - 2, P - 3 cells 1, 2, 3 |
+  // other interior patch 4 | boundary patch 5); -1: not listed
   // (one byte per node, cache resident, instead of three scattered reads per visit of a node)
   std::vector<int8_t> nkey(m.nnodes);
   parallel_for(m.nnodes, 1 << 16, [&](int64_t nd) {
@@ -781,14 +783,15 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
       return;
     }
     const bool interior = m.h_node_ncells[nd] == m.h_node_nfcts[nd]; // no boundary facet at the node
-    nkey[nd] = (int8_t)(3 * b_ + (interior ? ((m.h_node_ncells[nd] == eqlb::BIN_P[b_]) ? 0 : 1) : 2));
+    const int missing = eqlb::BIN_P[b_] - m.h_node_ncells[nd];         // idle lanes of the patch group
+    nkey[nd] = (int8_t)(NCL * b_ + (interior ? ((missing >= 0 && missing <= 3) ? missing : 4) : 5));
   });
   tile_chunks([&](int64_t t0, int64_t t1) {
     std::vector<int32_t> stamp(m.nnodes, -1), seen(3 * (size_t)TC);
     for (int64_t t = t0; t < t1; ++t)
     {
       int nseen = 0;
-      int32_t* cnt = &tcount[(size_t)t * 3 * NB];
+      int32_t* cnt = &tcount[(size_t)t * NCL * NB];
       auto key = [&](int32_t nd) { return (int)nkey[nd]; };
       for (int q = 0; q < TC; ++q)
       {
@@ -807,8 +810,8 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
           ++cnt[key(nd)];
         }
       }
-      int32_t pos[3 * NB], acc = 0; // stable counting sort by (bin, full first, then the other interior patches)
-      for (int q = 0; q < 3 * NB; ++q)
+      int32_t pos[NCL * NB], acc = 0; // stable counting sort by (bin, class)
+      for (int q = 0; q < NCL * NB; ++q)
       {
         pos[q] = acc;
         acc += cnt[q];
@@ -818,16 +821,25 @@ int build_tiles(eqlb_se* h, const std::vector<int8_t>& node_bin_all, eqlb::Build
         out[pos[key(seen[i])]++] = seen[i];
       for (int b_ = 0; b_ < NB; ++b_)
       {
-        tiles[t].nfull[b_] = cnt[3 * b_];
-        tiles[t].nint[b_] = cnt[3 * b_] + cnt[3 * b_ + 1];
-        tiles[t].npatch[b_] = cnt[3 * b_] + cnt[3 * b_ + 1] + cnt[3 * b_ + 2];
+        const int32_t* cb = cnt + NCL * b_;
+        tiles[t].nfull[b_] = cb[0];
+        tiles[t].nint[b_] = cb[0] + cb[1] + cb[2] + cb[3] + cb[4];
+        tiles[t].npatch[b_] = tiles[t].nint[b_] + cb[5];
+        if (b_ < 2)
+        {
+          tiles[t].nval[b_][0] = cb[0] + cb[1];
+          tiles[t].nval[b_][1] = cb[0] + cb[1] + cb[2];
+          tiles[t].nval[b_][2] = cb[0] + cb[1] + cb[2] + cb[3];
+        }
         if (full_only)
         {
           // whole wave-blocks: nint keeps the number of real patches, the others are copies (pass 2)
           const int per = 64 / eqlb::BIN_P[b_];
-          const int padded = (per > 0) ? (cnt[3 * b_] + per - 1) / per * per : cnt[3 * b_];
+          const int padded = (per > 0) ? (cb[0] + per - 1) / per * per : cb[0];
           tiles[t].nfull[b_] = padded;
           tiles[t].npatch[b_] = padded;
+          if (b_ < 2)
+            tiles[t].nval[b_][0] = tiles[t].nval[b_][1] = tiles[t].nval[b_][2] = padded;
         }
       }
     }

@@ -109,6 +109,9 @@ struct TileDesc
   int32_t npatch[MAX_BINS];
   int32_t nfull[MAX_BINS]; // leading patches of the bin that are interior with exactly P cells
   int32_t nint[MAX_BINS];  // leading patches that are interior (no boundary facet), nfull of them full
+  // behind the full ones the interior patches are ordered by their number of cells: nval[b][j] = end (in patches of the
+  // bin) of those with P - 1 - j cells, j = 0, 1, 2; the other interior patches follow up to nint (bins 0, 1 only)
+  int32_t nval[2][3];
   int32_t zero;            // 1: a vertex of an owned cell is not equilibrated here (node mask): its row
                            // is never written, the LDS slots of the tile are zeroed first
 };

@@ -185,46 +185,53 @@ __device__ __forceinline__ void pcr_apply(double (&r)[NC], const PcrMult<P>& m)
 #ifndef EQLB_STRESS_ROTATED
 #define EQLB_STRESS_ROTATED 1
 #endif
+#ifndef EQLB_STRESS_NFIX
+#define EQLB_STRESS_NFIX 1 // MIXED kernel: instances for interior patches with P - 1, P - 2, P - 3 cells (0: generic instance)
+#endif
 __host__ __device__ constexpr bool rot_nz(int P, int L, int d)
 {
   const int dd = ((d % P) + P) % P, dist = (dd < P - dd) ? dd : P - dd;
   return dist <= (1 << L);
 }
-template <int P, int S, int L>
-__device__ __forceinline__ void pcr_apply_level_rot(double (&r)[P], const PcrMult<P>& m)
+// (N <= P ring points - interior patches with N cells in groups of P lanes: offsets modulo N in the first N registers)
+template <int P, int N, int S, int L, int NA>
+__device__ __forceinline__ void pcr_apply_level_rot(double (&r)[NA], const PcrMult<P>& m)
 {
   if constexpr (P > S)
   {
-    double n[P];
+    double n[N];
 #pragma unroll
-    for (int d = 0; d < P; ++d)
+    for (int d = 0; d < N; ++d)
     {
-      double v = rot_nz(P, L, d) ? r[d] : 0.0;
-      if (rot_nz(P, L, d + S))
-        v = __builtin_fma(-m.al[L], dpp_d<0x110 + S>(r[(d + S) % P]), v);
-      if (rot_nz(P, L, d - S))
-        v = __builtin_fma(-m.ga[L], dpp_d<0x100 + S>(r[(d - S + P) % P]), v);
+      double v = rot_nz(N, L, d) ? r[d] : 0.0;
+      if (rot_nz(N, L, d + S))
+        v = __builtin_fma(-m.al[L], dpp_d<0x110 + S>(r[(d + S) % N]), v);
+      if (rot_nz(N, L, d - S))
+        v = __builtin_fma(-m.ga[L], dpp_d<0x100 + S>(r[((d - S) % N + N) % N]), v);
       n[d] = v;
     }
 #pragma unroll
-    for (int d = 0; d < P; ++d)
+    for (int d = 0; d < N; ++d)
       r[d] = n[d];
   }
 }
-template <int P>
-__device__ __forceinline__ void pcr_apply_rot(double (&r)[P], const PcrMult<P>& m)
+template <int P, int N, int NA>
+__device__ __forceinline__ void pcr_apply_rot(double (&r)[NA], const PcrMult<P>& m)
 {
-  pcr_apply_level_rot<P, 1, 0>(r, m);
-  pcr_apply_level_rot<P, 2, 1>(r, m);
-  pcr_apply_level_rot<P, 4, 2>(r, m);
+  pcr_apply_level_rot<P, N, 1, 0, NA>(r, m);
+  pcr_apply_level_rot<P, N, 2, 1, NA>(r, m);
+  pcr_apply_level_rot<P, N, 4, 2, NA>(r, m);
 #pragma unroll
-  for (int d = 0; d < P; ++d)
+  for (int d = 0; d < N; ++d)
     r[d] *= m.ibf;
 }
 
 // ---- the patch body ------------------------------------------------------------------------------------
 // lds: F | H | D | TE | WQ | HB (as k_se_patch_tiled) | V | VQ
-template <int P, bool FULL>
+// NFIX > 0 (with FULL = false): every patch of the wave-block is interior with exactly NFIX < P cells (the tile lists
+// are ordered by it) - the generic instance with the patch shape known at compile time: no node column, columns of B_k
+// stored by offset modulo NFIX like in the full-patch instance
+template <int P, bool FULL, int NFIX = 0>
 __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressRows& rows, const double* lds,
                                                   const int64_t lane_index, double* tile_slots, const int tc)
 {
@@ -247,7 +254,10 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
   const int sub = lane % P, gbase = lane - sub;
   const int64_t tl = lane_index;
   const int64_t patch_local = tl / P;
-  const bool pvalid = FULL ? true : (patch_local < a.npatch);
+  constexpr bool FIXN = !FULL && NFIX > 0;
+  constexpr bool INTK = FULL || FIXN;        // interior patches of a known size
+  constexpr int NR = FIXN ? NFIX : P;        // ring points (where known)
+  const bool pvalid = INTK ? true : (patch_local < a.npatch);
   const int64_t slot = a.slot_offset + tl;
   const int64_t patch = a.patch_offset + patch_local;
 
@@ -257,11 +267,13 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
   uint8_t flag0 = (uint8_t)PFLAG_INTERIOR;
   if (pvalid)
   {
-    if constexpr (!FULL)
+    if constexpr (!INTK)
     {
       n = (int)a.pn[patch];
       flag0 = a.pflag[patch];
     }
+    if constexpr (FIXN)
+      n = NFIX;
     cell_raw = a.slot_cell[slot];
     info = a.slot_info[slot];
   }
@@ -312,7 +324,7 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
   const double pf_m = (fm == 1) ? sgn : -sgn, pf_p = (fp == 1) ? sgn : -sgn;
 
   // ---- neighbours ----
-  const bool interior = FULL ? true : ((flag0 & PFLAG_INTERIOR) != 0);
+  const bool interior = INTK ? true : ((flag0 & PFLAG_INTERIOR) != 0);
   const int nf = interior ? n : n + 1;
   const int nn = (n > 0) ? n : 1;
   const int nextl = (sub + 1 < nn) ? sub + 1 : (interior ? 0 : sub);
@@ -678,20 +690,20 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
   {
     build_B(k, ci, (k == 0) ? J10 : -J00, (k == 0) ? J11 : -J01, Brow[k], bcn[k], Bd[k], Bdc[k]);
     // columns of B_k through the chain reduction: ring points, and the patch node on boundary patches
-    constexpr int NCEN = FULL ? 0 : 1;
-    constexpr bool ROT = FULL && EQLB_STRESS_ROTATED;
+    constexpr int NCEN = INTK ? 0 : 1;
+    constexpr bool ROT = INTK && EQLB_STRESS_ROTATED;
     double col[P + NCEN];
     if constexpr (ROT)
     {
-      // rotated storage (pcr_apply_rot): entry d = ring point (sub + d) mod P; lane 0 is no chain row
+      // rotated storage (pcr_apply_rot): entry d = ring point (sub + d) mod NR; lane 0 (and lanes >= NR) are no chain rows
       const double mch = in_chain ? 1.0 : 0.0;
 #pragma unroll
-      for (int d = 0; d < P; ++d)
+      for (int d = 0; d < P + NCEN; ++d)
         col[d] = 0.0;
       col[0] = mch * Brow[k][1];
       col[1] = mch * Brow[k][2];
-      col[P - 1] = mch * Brow[k][0];
-      pcr_apply_rot<P>(col, mult);
+      col[NR - 1] = mch * Brow[k][0];
+      pcr_apply_rot<P, NR, P + NCEN>(col, mult);
     }
     else
     {
@@ -701,7 +713,7 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
       const double v = (c == sub) ? Brow[k][1] : ((c == cm1) ? Brow[k][0] : ((c == cp1) ? Brow[k][2] : 0.0));
       col[c] = (in_chain && c < nf) ? v : 0.0;
     }
-    if constexpr (!FULL)
+    if constexpr (!INTK)
       col[P] = in_chain ? bcn[k] : 0.0;
     pcr_apply<P, P + NCEN>(col, mult);
     }
@@ -726,12 +738,12 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
       // rv[1 + d] collects S[sub][(sub + d) mod P] here (turned into ring-point order behind the loop over k):
       // the row before this lane holds that column at offset d + 1, the row after it at offset d - 1
 #pragma unroll
-      for (int d = 0; d < P; ++d)
+      for (int d = 0; d < NR; ++d)
       {
         double v = Brow[k][1] * col[d];
-        v += ring_prev(Brow[k][2] * col[(d + 1) % P]);
-        v += ring_next_nc(Brow[k][0] * col[(d + P - 1) % P]);
-        const int src = gbase + ((sub + d) & (P - 1));
+        v += ring_prev(Brow[k][2] * col[(d + 1) % NR]);
+        v += ring_next_nc(Brow[k][0] * col[(d + NR - 1) % NR]);
+        const int src = gbase + (FULL ? ((sub + d) & (P - 1)) : ((sub + d >= NR) ? sub + d - NR : sub + d));
         v = __builtin_fma(q1, from_lane(z1, src), __builtin_fma(q0, from_lane(z0, src), v));
         asm volatile("" : "+v"(v)); // keeps the exchanges of the columns apart (register pressure)
         rv[1 + d] += v;
@@ -753,7 +765,7 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
       rv[1 + c] += v;
     }
     }
-    if constexpr (!FULL)
+    if constexpr (!INTK)
     {
       // the patch node (needed on boundary patches): dense column, all rows E_i carry bcn_i
       const double bch = in_chain ? bcn[k] : 0.0;
@@ -765,23 +777,23 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
       rn[0] += group_sum_d<P>(bch * tn, gbase, sub) + qn0 * zn0 + qn1 * zn1;
     }
   }
-  if constexpr (FULL && EQLB_STRESS_ROTATED)
+  if constexpr (INTK && EQLB_STRESS_ROTATED)
   {
-    // S[sub][c] = rotated[(c - sub) mod P]: a rotation of the P registers by `sub`, one conditional step per bit
+    // S[sub][c] = rotated[(c - sub) mod NR]: a rotation of the NR registers by `sub`, one conditional step per bit
 #pragma unroll
-    for (int st = 1; st < P; st <<= 1)
+    for (int st = 1; st < NR; st <<= 1)
     {
       const bool bit = (sub & st) != 0;
-      double t_[P];
+      double t_[NR];
 #pragma unroll
-      for (int c = 0; c < P; ++c)
-        t_[c] = bit ? rv[1 + (c - st + P) % P] : rv[1 + c];
+      for (int c = 0; c < NR; ++c)
+        t_[c] = bit ? rv[1 + ((c - st) % NR + NR) % NR] : rv[1 + c];
 #pragma unroll
-      for (int c = 0; c < P; ++c)
+      for (int c = 0; c < NR; ++c)
         rv[1 + c] = t_[c];
     }
   }
-  if constexpr (!FULL)
+  if constexpr (!INTK)
   {
 #pragma unroll
     for (int c = 0; c < P; ++c)
@@ -858,7 +870,7 @@ __device__ __forceinline__ void stress_patch_body(const SeArgs& a, const StressR
           rv[c] -= f * pr[c];
       }
       gam_own = rv[NPT] * dinv;
-      if constexpr (FULL)
+      if constexpr (INTK)
         gam0 = rn[NPT] * rcp_d(rn[0]);
       else
       {
@@ -1064,13 +1076,41 @@ k_se_stress_tiled(const SeArgs a0, const TileArgs ta, const StressRows rows)
     a.slot_offset = td.slot_start[B];                                                               \
     a.patch_offset = td.patch_start[B];                                                             \
     const int nwb_full = MIXED ? ((td.nfull[B] * PP) >> 6) : nwb;                                   \
-    /* two loops, not one loop with a branch: the register allocation of the full-patch instance (no spills \
-       on its own) is then not tied to the generic one (same wave-block -> wave assignment) */         \
+    /* separate loops, not one loop with a branch: the register allocation of the full-patch instance (no spills \
+       on its own) is then not tied to the others (same wave-block -> wave assignment) */            \
     for (; u < nwb_full; u += NW)                                                                   \
       stress_patch_body<PP, true>(a, rows, lds, (int64_t)u * 64 + lane, sSlots, TC);                \
     if constexpr (MIXED)                                                                            \
+    {                                                                                               \
+      /* interior patches with PP - 1, PP - 2, PP - 3 cells (the tile lists are ordered by it): the whole wave-blocks \
+         inside their ranges run the instance with that patch size at compile time */                \
+      constexpr int PER = 64 / PP;                                                                  \
+      int c0[3], c1[3];                                                                             \
+      _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                 \
+      {                                                                                             \
+        const int first = (j == 0) ? td.nfull[B] : td.nval[B][j - 1];                               \
+        c0[j] = (first + PER - 1) / PER;                                                            \
+        c1[j] = (EQLB_STRESS_NFIX && PP - 1 - j >= 3) ? td.nval[B][j] / PER : 0;                    \
+        if (c1[j] < c0[j])                                                                          \
+          c1[j] = c0[j];                                                                            \
+      }                                                                                             \
+      if constexpr (EQLB_STRESS_NFIX && PP - 1 >= 3)                                                \
+        for (int v = c0[0] + wave; v < c1[0]; v += NW)                                              \
+          stress_patch_body<PP, false, PP - 1>(a, rows, lds, (int64_t)v * 64 + lane, sSlots, TC);   \
+      if constexpr (EQLB_STRESS_NFIX && PP - 2 >= 3)                                                \
+        for (int v = c0[1] + ((wave + 3) & (NW - 1)); v < c1[1]; v += NW)                           \
+          stress_patch_body<PP, false, (PP - 2 >= 3 ? PP - 2 : 0)>(a, rows, lds, (int64_t)v * 64 + lane, sSlots, TC); \
+      if constexpr (EQLB_STRESS_NFIX && PP - 3 >= 3)                                                \
+        for (int v = c0[2] + ((wave + 5) & (NW - 1)); v < c1[2]; v += NW)                           \
+          stress_patch_body<PP, false, (PP - 3 >= 3 ? PP - 3 : 0)>(a, rows, lds, (int64_t)v * 64 + lane, sSlots, TC); \
+      /* everything else: the generic instance */                                                   \
       for (; u < nwb; u += NW)                                                                      \
+      {                                                                                             \
+        if ((u >= c0[0] && u < c1[0]) || (u >= c0[1] && u < c1[1]) || (u >= c0[2] && u < c1[2]))    \
+          continue;                                                                                 \
         stress_patch_body<PP, false>(a, rows, lds, (int64_t)u * 64 + lane, sSlots, TC);             \
+      }                                                                                             \
+    }                                                                                               \
     u -= nwb;                                                                                       \
   }
   EQLB_STRESS_BIN(0, 4)
